@@ -1,0 +1,131 @@
+/*
+ * oracle_cli.c -- TEST INFRASTRUCTURE ONLY (see seqkit_oracle.h).
+ *
+ * `seqkit_oracle seq|fx2tab|stats [flags] [files...]`: the three reference commands
+ * on the CPU restatement, with the reference's flag letters
+ * (seqkit/cmd/seq.go:291-306, fx2tab.go:157-164, stat.go:292-294, root.go:65-72).
+ * Used by the tests to produce expected bytes and by bench.py as the timed CPU
+ * baseline; never by the product.
+ */
+#include "seqkit_oracle.h"
+
+#include <stdlib.h>
+#include <string.h>
+#include <strings.h>
+
+static int usage(void)
+{
+    fprintf(stderr, "usage: seqkit_oracle seq|fx2tab|stats [flags] [files...]\n");
+    return 255;
+}
+
+/* accepts "-x", "--long", and a value either as the next argument or after '=' */
+static int is_flag(const char *a, const char *s, const char *l)
+{
+    if (s && strcmp(a, s) == 0) return 1;
+    if (l && strcmp(a, l) == 0) return 1;
+    return 0;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 2) return usage();
+    const char *cmd = argv[1];
+    const char *files[1024]; int nfiles = 0;
+    const char *base[64]; int nbase = 0;
+    ora_seq_opts so = {0}; so.line_width = 60; so.min_len = so.max_len = -1; so.alphabet = -1; so.guess_len = 10000;
+    ora_fx2tab_opts fo = {0}; fo.guess_len = 10000;
+    ora_stats_opts to = {0}; to.gap_letters = "- ."; to.guess_len = 10000;
+    const char *outfile = "-";
+    int is_seq = !strcmp(cmd, "seq"), is_fx = !strcmp(cmd, "fx2tab"),
+        is_st = !strcmp(cmd, "stats") || !strcmp(cmd, "stat");
+    if (!is_seq && !is_fx && !is_st) return usage();
+
+    for (int i = 2; i < argc; i++) {
+        const char *a = argv[i];
+        if (a[0] != '-' || !strcmp(a, "-")) { if (nfiles < 1024) files[nfiles++] = a; continue; }
+        /* bundled short bool flags, e.g. -rp or -nlg */
+        if (a[1] != '-' && strlen(a) > 2) {
+            int all_bool = 1;
+            for (const char *p = a + 1; *p; p++) if (!strchr("rpnsqilgGHaT", *p)) all_bool = 0;
+            if (all_bool && !(is_st && strchr(a, 'G')) && !(is_seq && strchr(a, 'G'))) {
+                char one[3] = {'-', 0, 0};
+                int rc = 0;
+                for (const char *p = a + 1; *p; p++) {
+                    one[1] = *p;
+                    char *sub[3] = {argv[0], argv[1], one};
+                    (void)sub; rc = 0;
+                    if (is_seq) {
+                        if (*p == 'r') so.reverse = 1; else if (*p == 'p') so.complement = 1;
+                        else if (*p == 'n') so.only_name = 1; else if (*p == 's') so.only_seq = 1;
+                        else if (*p == 'q') so.only_qual = 1; else if (*p == 'i') so.only_id = 1;
+                        else rc = 1;
+                    } else if (is_fx) {
+                        if (*p == 'l') fo.length = 1; else if (*p == 'g') fo.gc = 1;
+                        else if (*p == 'G') fo.gc_skew = 1; else if (*p == 'n') fo.only_name = 1;
+                        else if (*p == 'i') fo.only_id = 1; else if (*p == 'H') fo.header_line = 1;
+                        else if (*p == 'a') fo.alphabet_col = 1; else rc = 1;
+                    } else {
+                        if (*p == 'a') to.all = 1; else if (*p == 'T') to.tabular = 1; else rc = 1;
+                    }
+                    if (rc) { fprintf(stderr, "unknown flag in %s\n", a); return 255; }
+                }
+                continue;
+            }
+        }
+#define NEXT() (i + 1 < argc ? argv[++i] : (fprintf(stderr, "flag %s needs a value\n", a), exit(255), ""))
+        if (is_flag(a, "-o", "--out-file")) { outfile = NEXT(); continue; }
+        if (is_flag(a, "-w", "--line-width")) { so.line_width = atoi(NEXT()); continue; }
+        if (is_flag(a, "-j", "--threads")) { (void)NEXT(); continue; }
+        if (is_flag(a, NULL, "--quiet")) continue;
+        if (is_flag(a, NULL, "--alphabet-guess-seq-length")) {
+            size_t v = (size_t)atoll(NEXT()); so.guess_len = fo.guess_len = to.guess_len = v; continue;
+        }
+        if (is_flag(a, "-t", "--seq-type")) {
+            const char *v = NEXT();
+            if (!strcasecmp(v, "dna")) so.alphabet = ORA_ALPHABET_DNAredundant;
+            else if (!strcasecmp(v, "rna")) so.alphabet = ORA_ALPHABET_RNAredundant;
+            else if (!strcasecmp(v, "protein")) so.alphabet = ORA_ALPHABET_Protein;
+            else if (!strcasecmp(v, "unlimit")) so.alphabet = ORA_ALPHABET_Unlimit;
+            else so.alphabet = -1;
+            continue;
+        }
+        if (is_seq) {
+            if (is_flag(a, "-r", "--reverse")) { so.reverse = 1; continue; }
+            if (is_flag(a, "-p", "--complement")) { so.complement = 1; continue; }
+            if (is_flag(a, "-n", "--name")) { so.only_name = 1; continue; }
+            if (is_flag(a, "-s", "--seq")) { so.only_seq = 1; continue; }
+            if (is_flag(a, "-q", "--qual")) { so.only_qual = 1; continue; }
+            if (is_flag(a, "-i", "--only-id")) { so.only_id = 1; continue; }
+            if (is_flag(a, "-m", "--min-len")) { so.min_len = atoi(NEXT()); continue; }
+            if (is_flag(a, "-M", "--max-len")) { so.max_len = atoi(NEXT()); continue; }
+        } else if (is_fx) {
+            if (is_flag(a, "-l", "--length")) { fo.length = 1; continue; }
+            if (is_flag(a, "-g", "--gc")) { fo.gc = 1; continue; }
+            if (is_flag(a, "-G", "--gc-skew")) { fo.gc_skew = 1; continue; }
+            if (is_flag(a, "-n", "--name")) { fo.only_name = 1; continue; }
+            if (is_flag(a, "-i", "--only-id")) { fo.only_id = 1; continue; }
+            if (is_flag(a, "-H", "--header-line")) { fo.header_line = 1; continue; }
+            if (is_flag(a, "-a", "--alphabet")) { fo.alphabet_col = 1; continue; }
+            if (is_flag(a, "-B", "--base-content")) { if (nbase < 64) base[nbase++] = NEXT(); continue; }
+        } else {
+            if (is_flag(a, "-a", "--all")) { to.all = 1; continue; }
+            if (is_flag(a, "-T", "--tabular")) { to.tabular = 1; continue; }
+            if (is_flag(a, "-G", "--gap-letters")) { to.gap_letters = NEXT(); continue; }
+        }
+        fprintf(stderr, "unknown flag %s\n", a);
+        return 255;
+    }
+    if (nfiles == 0) files[nfiles++] = "-";   /* seqkit/cmd/helper.go:55-56 */
+    fo.nbase = nbase; fo.base = base;
+
+    FILE *out = stdout;
+    if (strcmp(outfile, "-") != 0 && !(out = fopen(outfile, "wb"))) { perror(outfile); return 255; }
+    static char obuf[1 << 20];
+    setvbuf(out, obuf, _IOFBF, sizeof obuf);
+    int rc = is_seq ? ora_cmd_seq(&so, nfiles, files, out, stderr)
+           : is_fx  ? ora_cmd_fx2tab(&fo, nfiles, files, out, stderr)
+                    : ora_cmd_stats(&to, nfiles, files, out, stderr);
+    if (out != stdout) fclose(out); else fflush(out);
+    return rc;
+}

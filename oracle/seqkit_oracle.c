@@ -1,0 +1,592 @@
+/*
+ * seqkit_oracle.c -- TEST INFRASTRUCTURE ONLY (see seqkit_oracle.h).
+ *
+ * CPU restatement of the SeqKit hot path.  Each function cites the reference call
+ * site it follows (paths relative to the reference checkout) and, where the
+ * arithmetic lives in an un-vendored Go module, names the module function whose
+ * published behaviour is restated.  Deliberately simple: one record at a time,
+ * byte loops, no threads -- the shape of the Go code, not of the GPU code.
+ */
+#include "seqkit_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <zlib.h>
+
+/* ------------------------------------------------------------------ alphabets */
+/* bio/seq alphabet.go (module github.com/shenwei356/bio, unpinned):
+ * NewAlphabet(name, isUnlimit, letters, pairs, gap, ambiguous). */
+typedef struct { const char *name; const char *letters; const char *pairs;
+                 const char *gap; const char *ambiguous; } alpha_def;
+
+static const alpha_def ALPHA[6] = {
+    {"DNA", "acgtACGT", "tgcaTGCA", " -.", "nN."},
+    {"DNAredundant", "acgtryswkmbdhvACGTRYSWKMBDHV", "tgcayrswmkvhdbTGCAYRSWMKVHDB", " -.", "nN."},
+    {"RNA", "acguACGU", "ugcaUGCA", " -.", "nN."},
+    {"RNAredundant", "acguryswkmbdhvACGURYSWKMBDHV", "ugcayrswmkvhdbUGCAYRSWMKVHDB", " -.", "nN."},
+    {"Protein", "abcdefghijklmnpqrstvwyzABCDEFGHIJKLMNPQRSTVWYZ*_.",
+                "abcdefghijklmnpqrstvwyzABCDEFGHIJKLMNPQRSTVWYZ*_.", " -", "xX*_."},
+    {"Unlimit", "", "", "", ""},
+};
+
+const char *ora_alphabet_name(int a) { return (a >= 0 && a < 6) ? ALPHA[a].name : ""; }
+
+void ora_alphabet_members(int a, uint8_t m[256])
+{
+    memset(m, 0, 256);
+    if (a < 0 || a >= 6) return;
+    for (const char *p = ALPHA[a].letters; *p; p++) m[(uint8_t)*p] = 1;
+    for (const char *p = ALPHA[a].gap; *p; p++) m[(uint8_t)*p] = 1;
+    for (const char *p = ALPHA[a].ambiguous; *p; p++) m[(uint8_t)*p] = 1;
+}
+
+/* Alphabet.PairLetter: letters -> pairs, gap and ambiguous letters -> themselves.
+ * A byte outside the table makes PairLetter return an error that
+ * ComplementInplace ignores; the byte is left as it was (parity unpinned: no
+ * vector in the reference tree complements a letter outside its alphabet). */
+void ora_pair_table(int a, uint8_t lut[256])
+{
+    for (int i = 0; i < 256; i++) lut[i] = (uint8_t)i;
+    if (a < 0 || a >= 6 || a == ORA_ALPHABET_Unlimit) return;
+    const char *l = ALPHA[a].letters, *p = ALPHA[a].pairs;
+    for (size_t i = 0; l[i]; i++) lut[(uint8_t)l[i]] = (uint8_t)p[i];
+}
+
+/* seq.GuessAlphabet + GuessAlphabetLessConservatively (bio/seq): the set of
+ * distinct bytes of the prefix is tested for inclusion in DNA, RNA, DNAredundant,
+ * RNAredundant, Protein, in that order; empty -> Unlimit; DNA/RNA are promoted to
+ * their redundant forms.  Pinned by tests/test.sh:34-57 and doc/docs/usage.md:303-317. */
+int ora_guess_alphabet(const uint8_t *seq, size_t n, size_t threshold)
+{
+    if (n == 0) return ORA_ALPHABET_Unlimit;
+    if (threshold != 0 && n > threshold) n = threshold;
+    uint8_t present[256]; memset(present, 0, sizeof present);
+    for (size_t i = 0; i < n; i++) present[seq[i]] = 1;
+    static const int order[5] = {ORA_ALPHABET_DNA, ORA_ALPHABET_RNA, ORA_ALPHABET_DNAredundant,
+                                 ORA_ALPHABET_RNAredundant, ORA_ALPHABET_Protein};
+    for (int k = 0; k < 5; k++) {
+        uint8_t m[256]; ora_alphabet_members(order[k], m);
+        int ok = 1;
+        for (int b = 0; b < 256 && ok; b++) if (present[b] && !m[b]) ok = 0;
+        if (ok) {
+            if (order[k] == ORA_ALPHABET_DNA) return ORA_ALPHABET_DNAredundant;
+            if (order[k] == ORA_ALPHABET_RNA) return ORA_ALPHABET_RNAredundant;
+            return order[k];
+        }
+    }
+    return ORA_ALPHABET_Unlimit;
+}
+
+/* ------------------------------------------------------------------ transforms */
+/* seqkit/cmd/seq.go:187-189 -> (*Seq).ReverseInplace: byte swap from both ends;
+ * quality is reversed with the bases (doc/docs/download.md:156, v0.4.5 fix). */
+void ora_reverse_inplace(uint8_t *seq, uint8_t *qual, size_t n)
+{
+    for (size_t i = 0, j = n; i + 1 < j; i++) {
+        j--;
+        uint8_t t = seq[i]; seq[i] = seq[j]; seq[j] = t;
+        if (qual) { t = qual[i]; qual[i] = qual[j]; qual[j] = t; }
+    }
+}
+
+/* seqkit/cmd/seq.go:190-195 -> (*Seq).ComplementInplace: Seq[i] = PairLetter(Seq[i]). */
+void ora_complement_inplace(uint8_t *seq, size_t n, int alphabet)
+{
+    uint8_t lut[256]; ora_pair_table(alphabet, lut);
+    for (size_t i = 0; i < n; i++) seq[i] = lut[seq[i]];
+}
+
+/* seqkit/cmd/locate.go:154, subseq.go:399 -> RevCom; equals -r then -p (tests/test.sh:79-84). */
+void ora_revcom_inplace(uint8_t *seq, uint8_t *qual, size_t n, int alphabet)
+{
+    ora_reverse_inplace(seq, qual, n);
+    ora_complement_inplace(seq, n, alphabet);
+}
+
+/* ------------------------------------------------------------------ counting */
+static uint64_t count_byte(const uint8_t *s, size_t n, uint8_t b)
+{
+    uint64_t c = 0;
+    for (size_t i = 0; i < n; i++) c += (s[i] == b);
+    return c;
+}
+
+/* (*Seq).BaseContent numerator: for every byte of `list` (duplicates count again),
+ * occurrences of its upper-case form plus, if different, of its lower-case form. */
+uint64_t ora_base_count(const uint8_t *seq, size_t n, const char *list)
+{
+    uint64_t sum = 0;
+    for (const char *p = list; *p; p++) {
+        uint8_t b = (uint8_t)*p, up = b, lo = b;
+        if (b >= 'a' && b <= 'z') up = (uint8_t)(b - 32);
+        if (b >= 'A' && b <= 'Z') lo = (uint8_t)(b + 32);
+        sum += count_byte(seq, n, up);
+        if (lo != up) sum += count_byte(seq, n, lo);
+    }
+    return sum;
+}
+
+/* seqkit/cmd/fx2tab.go:128,129,141: float64(sum)/float64(len); 0 for an empty record. */
+double ora_base_content(const uint8_t *seq, size_t n, const char *list)
+{
+    if (n == 0) return 0.0;
+    return (double)ora_base_count(seq, n, list) / (double)n;
+}
+
+/* seqkit/cmd/stat.go:125 -> byteutil.CountBytes: bytes of seq that are in `letters`. */
+uint64_t ora_count_bytes(const uint8_t *seq, size_t n, const uint8_t *letters, size_t nletters)
+{
+    uint8_t in[256]; memset(in, 0, sizeof in);
+    for (size_t i = 0; i < nletters; i++) in[letters[i]] = 1;
+    uint64_t c = 0;
+    for (size_t i = 0; i < n; i++) c += in[seq[i]];
+    return c;
+}
+
+/* ------------------------------------------------------------------ formatting */
+/* seqkit/cmd/seq.go:243-253 -> byteutil.WrapByteSlice: '\n' after every `width`
+ * bytes except after the last line (tests/test.sh:22-26 pins len%width==0). */
+size_t ora_wrap(const uint8_t *s, size_t n, int width, uint8_t *out)
+{
+    if (width < 1 || n == 0) { memcpy(out, s, n); return n; }
+    size_t w = (size_t)width, o = 0;
+    for (size_t i = 0; i < n; i += w) {
+        size_t k = n - i < w ? n - i : w;
+        if (i) out[o++] = '\n';
+        memcpy(out + o, s + i, k); o += k;
+    }
+    return o;
+}
+
+/* util/math.Round: trunc((f + 0.5/10^n) * 10^n) / 10^n  (seqkit/cmd/stat.go:158). */
+double ora_round(double f, int n)
+{
+    double p = pow(10.0, n);
+    return trunc((f + 0.5 / p) * p) / p;
+}
+
+/* seqkit/cmd/stat.go:297-306 */
+int64_t ora_median(const int64_t *sorted, size_t l)
+{
+    if (l == 0) return 0;
+    if (l % 2 == 0) return (sorted[l / 2 - 1] + sorted[l / 2]) / 2;
+    return sorted[l / 2];
+}
+
+/* seqkit/cmd/stat.go:308-326 */
+void ora_quartile(const int64_t *sorted, size_t l, int64_t *q1, int64_t *q2, int64_t *q3)
+{
+    *q1 = *q2 = *q3 = 0;
+    if (l == 0) return;
+    size_t c1, c2;
+    if (l % 2 == 0) { c1 = l / 2; c2 = l / 2; } else { c1 = (l - 1) / 2; c2 = c1 + 1; }
+    *q1 = ora_median(sorted, c1);
+    *q2 = ora_median(sorted, l);
+    *q3 = ora_median(sorted + c2, l - c2);
+}
+
+/* seqkit/cmd/stat.go:136-145 */
+void ora_n50(const int64_t *sorted, size_t num, int64_t len_sum, int64_t *n50, int64_t *l50)
+{
+    int64_t sum = 0; *n50 = 0; *l50 = 0;
+    for (size_t k = num; k-- > 0;) {
+        sum += sorted[k];
+        if ((sum << 1) >= len_sum) { *n50 = sorted[k]; *l50 = (int64_t)(num - k); break; }
+    }
+}
+
+/* go-humanize Comma(int64) */
+void ora_comma(int64_t v, char *buf)
+{
+    char d[32]; int neg = v < 0; uint64_t u = neg ? (uint64_t)(-(v + 1)) + 1 : (uint64_t)v;
+    int n = snprintf(d, sizeof d, "%llu", (unsigned long long)u), o = 0;
+    if (neg) buf[o++] = '-';
+    for (int i = 0; i < n; i++) { if (i && (n - i) % 3 == 0) buf[o++] = ','; buf[o++] = d[i]; }
+    buf[o] = 0;
+}
+
+/* Go strconv.FormatFloat(v,'f',-1,64): shortest digits that round-trip. */
+static void fmt_shortest_f(double v, char *buf)
+{
+    for (int prec = 0; prec <= 20; prec++) {
+        snprintf(buf, 64, "%.*f", prec, v);
+        if (strtod(buf, NULL) == v) return;
+    }
+}
+
+/* go-humanize Commaf(float64): commas in the integer part of the shortest form. */
+void ora_commaf(double v, char *buf)
+{
+    char t[64]; int o = 0;
+    if (v < 0) { buf[o++] = '-'; v = -v; }
+    fmt_shortest_f(v, t);
+    char *dot = strchr(t, '.'); int n = dot ? (int)(dot - t) : (int)strlen(t);
+    for (int i = 0; i < n; i++) { if (i && (n - i) % 3 == 0) buf[o++] = ','; buf[o++] = t[i]; }
+    if (dot) { strcpy(buf + o, dot); return; }
+    buf[o] = 0;
+}
+
+/* Go fmt "%.Nf": correctly rounded like C's, but NaN/Inf are spelled NaN/+Inf/-Inf. */
+void ora_fmt_fixed(double v, int prec, char *buf)
+{
+    if (isnan(v)) { strcpy(buf, "NaN"); return; }
+    if (isinf(v)) { strcpy(buf, v > 0 ? "+Inf" : "-Inf"); return; }
+    snprintf(buf, 400, "%.*f", prec, v);
+}
+
+/* ------------------------------------------------------------------ reader */
+/* bio/seqio/fastx Reader restated: the format is decided by the first non-blank
+ * byte ('>' FASTA, '@' FASTQ); a FASTA record runs to the next line starting with
+ * '>'; '\r' and '\n' are dropped from the sequence, every other byte (interior
+ * spaces included, doc/docs/usage.md:307-309) is kept; FASTQ is read as
+ * head / sequence lines up to the '+' line / quality lines until as many quality
+ * bytes as bases were read.  ID = leading run of non-space bytes of the head
+ * (default --id-regexp "^([^\s]+)\s?", seqkit/cmd/root.go:68). */
+struct ora_reader {
+    gzFile fh;
+    uint8_t *line; size_t line_cap; size_t line_len; int have_line; int eof;
+    int is_fastq; int format_known;
+    int alphabet; int forced_alphabet; size_t guess_threshold;
+    uint8_t *name, *seq, *qual; size_t name_cap, seq_cap, qual_cap;
+};
+
+static int grow(uint8_t **p, size_t *cap, size_t need)
+{
+    if (need <= *cap) return 0;
+    size_t c = *cap ? *cap : 256;
+    while (c < need) c *= 2;
+    uint8_t *q = (uint8_t *)realloc(*p, c);
+    if (!q) return -1;
+    *p = q; *cap = c; return 0;
+}
+
+/* reads one line without its "\n" / "\r\n"; returns 0 at EOF */
+static int read_line(ora_reader *r)
+{
+    if (r->have_line) return 1;
+    if (r->eof) return 0;
+    r->line_len = 0;
+    for (;;) {
+        if (grow(&r->line, &r->line_cap, r->line_len + 65536) < 0) return 0;
+        if (!gzgets(r->fh, (char *)r->line + r->line_len, (int)(r->line_cap - r->line_len))) {
+            r->eof = 1;
+            if (r->line_len == 0) return 0;
+            break;
+        }
+        r->line_len += strlen((char *)r->line + r->line_len);
+        if (r->line_len && r->line[r->line_len - 1] == '\n') break;
+    }
+    while (r->line_len && (r->line[r->line_len - 1] == '\n' || r->line[r->line_len - 1] == '\r'))
+        r->line_len--;
+    r->have_line = 1;
+    return 1;
+}
+
+ora_reader *ora_reader_open(const char *path, int forced_alphabet, size_t guess_threshold)
+{
+    ora_reader *r = (ora_reader *)calloc(1, sizeof *r);
+    if (!r) return NULL;
+    r->fh = (strcmp(path, "-") == 0) ? gzdopen(0, "rb") : gzopen(path, "rb");
+    if (!r->fh) { free(r); return NULL; }
+    gzbuffer(r->fh, 1 << 20);
+    r->alphabet = -1; r->forced_alphabet = forced_alphabet; r->guess_threshold = guess_threshold;
+    return r;
+}
+
+static size_t id_length(const uint8_t *name, size_t n)
+{
+    size_t i = 0;
+    while (i < n && !(name[i] == ' ' || (name[i] >= '\t' && name[i] <= '\r'))) i++;
+    return i == 0 ? n : i;   /* regexp does not match -> whole head */
+}
+
+int ora_reader_next(ora_reader *r, ora_record *rec)
+{
+    /* skip blank lines between records */
+    for (;;) {
+        if (!read_line(r)) return 0;
+        if (r->line_len) break;
+        r->have_line = 0;
+    }
+    if (!r->format_known) {
+        if (r->line[0] == '>') r->is_fastq = 0;
+        else if (r->line[0] == '@') r->is_fastq = 1;
+        else return -1;
+        r->format_known = 1;
+    }
+    if (r->line[0] != (r->is_fastq ? '@' : '>')) return -1;
+    size_t nl = r->line_len - 1;
+    if (grow(&r->name, &r->name_cap, nl + 1) < 0) return -2;
+    memcpy(r->name, r->line + 1, nl);
+    r->have_line = 0;
+    size_t sl = 0, ql = 0;
+    if (!r->is_fastq) {
+        while (read_line(r)) {
+            if (r->line_len && r->line[0] == '>') break;
+            if (grow(&r->seq, &r->seq_cap, sl + r->line_len + 1) < 0) return -2;
+            for (size_t i = 0; i < r->line_len; i++)
+                if (r->line[i] != '\r' && r->line[i] != '\n') r->seq[sl++] = r->line[i];
+            r->have_line = 0;
+        }
+    } else {
+        while (read_line(r)) {
+            if (r->line_len && r->line[0] == '+') { r->have_line = 0; break; }
+            if (grow(&r->seq, &r->seq_cap, sl + r->line_len + 1) < 0) return -2;
+            memcpy(r->seq + sl, r->line, r->line_len); sl += r->line_len;
+            r->have_line = 0;
+        }
+        while (ql < sl && read_line(r)) {
+            if (grow(&r->qual, &r->qual_cap, ql + r->line_len + 1) < 0) return -2;
+            memcpy(r->qual + ql, r->line, r->line_len); ql += r->line_len;
+            r->have_line = 0;
+        }
+        if (ql != sl) return -3;
+    }
+    if (r->alphabet < 0)
+        r->alphabet = r->forced_alphabet >= 0 ? r->forced_alphabet
+                                              : ora_guess_alphabet(r->seq, sl, r->guess_threshold);
+    rec->name = r->name; rec->name_len = nl; rec->id_len = id_length(r->name, nl);
+    rec->seq = r->seq; rec->seq_len = sl;
+    rec->qual = r->qual; rec->qual_len = ql;
+    return 1;
+}
+
+int ora_reader_is_fastq(const ora_reader *r) { return r->is_fastq; }
+int ora_reader_alphabet(const ora_reader *r) { return r->alphabet; }
+
+void ora_reader_close(ora_reader *r)
+{
+    if (!r) return;
+    gzclose(r->fh);
+    free(r->line); free(r->name); free(r->seq); free(r->qual); free(r);
+}
+
+/* ------------------------------------------------------------------ seq */
+/* seqkit/cmd/seq.go:114-280, flags -r -p -n -s -q -i -m -M -w. */
+int ora_cmd_seq(const ora_seq_opts *o, int nfiles, const char **files, FILE *out, FILE *err)
+{
+    uint8_t *wrapbuf = NULL; size_t wrapcap = 0;
+    int is_fastq = 0, check_type = 1;
+    for (int f = 0; f < nfiles; f++) {
+        ora_reader *r = ora_reader_open(files[f], o->alphabet, o->guess_len);
+        if (!r) { fprintf(err, "[ERRO] open %s: no such file or directory\n", files[f]); return 255; }
+        ora_record rec; int rc;
+        while ((rc = ora_reader_next(r, &rec)) == 1) {
+            if (o->min_len >= 0 && rec.seq_len < (size_t)o->min_len) continue;
+            if (o->max_len >= 0 && rec.seq_len > (size_t)o->max_len) continue;
+            int width = ora_reader_is_fastq(r) ? 0 : o->line_width;       /* seq.go:136-138 */
+            if (check_type) { is_fastq = rec.qual_len > 0; check_type = 0; } /* seq.go:140-145 */
+            int pq = is_fastq, pn = 1, ps = 1;
+            if (o->only_name && o->only_seq) { pn = ps = 1; }
+            else if (o->only_name) { pn = 1; ps = 0; pq = 0; }
+            else if (o->only_seq) { pn = 0; ps = 1; pq = 0; }
+            else if (o->only_qual) {
+                if (!is_fastq) {
+                    fprintf(err, "[ERRO] FASTA format has no quality. So do not just use flag -q (--qual)\n");
+                    ora_reader_close(r); free(wrapbuf); return 255;
+                }
+                pn = 0; ps = 0; pq = 1;
+            }
+            if (pn) {
+                size_t hl = o->only_id ? rec.id_len : rec.name_len;
+                if (ps) fputc(is_fastq ? '@' : '>', out);
+                fwrite(rec.name, 1, hl, out); fputc('\n', out);
+            }
+            int ab = ora_reader_alphabet(r);
+            if (o->reverse) ora_reverse_inplace(rec.seq, rec.qual_len ? rec.qual : NULL, rec.seq_len);
+            if (o->complement) {
+                if (ab == ORA_ALPHABET_Protein || ab == ORA_ALPHABET_Unlimit)
+                    fprintf(err, "[WARN] Complement does no take effect on protein/unlimit sequence\n");
+                ora_complement_inplace(rec.seq, rec.seq_len, ab);
+            }
+            size_t need = rec.seq_len + (width > 0 ? rec.seq_len / (size_t)width : 0) + 1;
+            if (need > wrapcap) { wrapbuf = (uint8_t *)realloc(wrapbuf, need); wrapcap = need; }
+            if (ps) {
+                size_t n = ora_wrap(rec.seq, rec.seq_len, width, wrapbuf);
+                fwrite(wrapbuf, 1, n, out); fputc('\n', out);
+            }
+            if (pq) {
+                if (!o->only_qual) fputs("+\n", out);
+                size_t n = ora_wrap(rec.qual, rec.qual_len, width, wrapbuf);
+                fwrite(wrapbuf, 1, n, out); fputc('\n', out);
+            }
+        }
+        ora_reader_close(r);
+        if (rc < 0) { fprintf(err, "[ERRO] error when parsing %s\n", files[f]); free(wrapbuf); return 255; }
+    }
+    free(wrapbuf);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ fx2tab */
+static int cmp_u8(const void *a, const void *b) { return (int)*(const uint8_t *)a - (int)*(const uint8_t *)b; }
+
+/* seqkit/cmd/fx2tab.go:68-149. */
+int ora_cmd_fx2tab(const ora_fx2tab_opts *o, int nfiles, const char **files, FILE *out, FILE *err)
+{
+    char num[400];
+    if (o->header_line) {
+        fputs("#name\tseq\tqual", out);
+        if (o->length) fputs("\tlength", out);
+        if (o->gc) fputs("\tGC", out);
+        if (o->gc_skew) fputs("\tGC-Skew", out);
+        for (int i = 0; i < o->nbase; i++) fprintf(out, "\t%s", o->base[i]);
+        if (o->alphabet_col) fputs("\talphabet", out);
+        fputc('\n', out);
+    }
+    for (int f = 0; f < nfiles; f++) {
+        ora_reader *r = ora_reader_open(files[f], -1, o->guess_len);
+        if (!r) { fprintf(err, "[ERRO] open %s: no such file or directory\n", files[f]); return 255; }
+        ora_record rec; int rc;
+        while ((rc = ora_reader_next(r, &rec)) == 1) {
+            fwrite(rec.name, 1, o->only_id ? rec.id_len : rec.name_len, out);
+            fputc('\t', out);
+            if (!o->only_name) fwrite(rec.seq, 1, rec.seq_len, out);
+            fputc('\t', out);
+            if (!o->only_name) fwrite(rec.qual, 1, rec.qual_len, out);
+            if (o->length) fprintf(out, "\t%zu", rec.seq_len);
+            double g = 0, c = 0;
+            if (o->gc || o->gc_skew) {                      /* two separate divisions */
+                g = ora_base_content(rec.seq, rec.seq_len, "G");
+                c = ora_base_content(rec.seq, rec.seq_len, "C");
+            }
+            if (o->gc) { ora_fmt_fixed((g + c) * 100, 2, num); fprintf(out, "\t%s", num); }
+            if (o->gc_skew) { ora_fmt_fixed((g - c) / (g + c) * 100, 2, num); fprintf(out, "\t%s", num); }
+            for (int i = 0; i < o->nbase; i++) {
+                ora_fmt_fixed(ora_base_content(rec.seq, rec.seq_len, o->base[i]) * 100, 2, num);
+                fprintf(out, "\t%s", num);
+            }
+            if (o->alphabet_col) {                           /* fx2tab.go:167-180 */
+                uint8_t present[256], letters[256]; int n = 0;
+                memset(present, 0, sizeof present);
+                for (size_t i = 0; i < rec.seq_len; i++) present[rec.seq[i]] = 1;
+                for (int b = 0; b < 256; b++) if (present[b]) letters[n++] = (uint8_t)b;
+                qsort(letters, (size_t)n, 1, cmp_u8);
+                fputc('\t', out); fwrite(letters, 1, (size_t)n, out);
+            }
+            fputc('\n', out);
+        }
+        ora_reader_close(r);
+        if (rc < 0) { fprintf(err, "[ERRO] error when parsing %s\n", files[f]); return 255; }
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------ stats */
+typedef struct { const char *file; const char *format; char type[16];
+                 int64_t num, len_sum, gap_sum, len_min, len_max, n50, l50, q1, q2, q3;
+                 double len_avg; } stat_info;
+
+static int cmp_i64(const void *a, const void *b)
+{
+    int64_t x = *(const int64_t *)a, y = *(const int64_t *)b;
+    return x < y ? -1 : x > y;
+}
+
+/* go-prettytable: every cell padded to its column's widest entry (header included),
+ * AlignRight columns padded on the left, columns joined by Separator, '\n' per row.
+ * Left-aligned padding of a LAST column is parity unpinned (stats ends in a
+ * right-aligned column, so it never occurs here). */
+static void pretty_table(FILE *out, int ncol, const int *align_right, int nrow, char ***cells)
+{
+    int width[16];
+    for (int c = 0; c < ncol; c++) {
+        width[c] = 0;
+        for (int r = 0; r < nrow; r++) { int l = (int)strlen(cells[r][c]); if (l > width[c]) width[c] = l; }
+    }
+    for (int r = 0; r < nrow; r++) {
+        for (int c = 0; c < ncol; c++) {
+            if (c) fputs("  ", out);                       /* stat.go:236 */
+            if (align_right[c]) fprintf(out, "%*s", width[c], cells[r][c]);
+            else fprintf(out, "%-*s", width[c], cells[r][c]);
+        }
+        fputc('\n', out);
+    }
+}
+
+/* seqkit/cmd/stat.go:78-268. */
+int ora_cmd_stats(const ora_stats_opts *o, int nfiles, const char **files, FILE *out, FILE *err)
+{
+    const char *gaps = o->gap_letters ? o->gap_letters : "- .";
+    if (!*gaps) { fprintf(err, "[ERRO] value of flag -G (--gap-letters) should not be empty\n"); return 255; }
+    for (const char *p = gaps; *p; p++)
+        if ((uint8_t)*p > 127) { fprintf(err, "[ERRO] value of -G (--gap-letters) contains non-ASCII characters\n"); return 255; }
+    stat_info *infos = (stat_info *)calloc((size_t)nfiles, sizeof *infos);
+    for (int f = 0; f < nfiles; f++) {
+        ora_reader *r = ora_reader_open(files[f], -1, o->guess_len);
+        if (!r) { fprintf(err, "[ERRO] open %s: no such file or directory\n", files[f]); free(infos); return 255; }
+        stat_info *s = &infos[f];
+        s->file = files[f]; s->format = ""; s->len_min = INT64_MAX;
+        int64_t *lens = NULL; size_t cap = 0;
+        ora_record rec; int rc;
+        while ((rc = ora_reader_next(r, &rec)) == 1) {
+            if (s->num == 0) s->format = rec.qual_len > 0 ? "FASTQ" : "FASTA";
+            int64_t l = (int64_t)rec.seq_len;
+            if (o->all) {
+                if ((size_t)s->num >= cap) { cap = cap ? cap * 2 : 1024; lens = (int64_t *)realloc(lens, cap * sizeof *lens); }
+                lens[s->num] = l;
+            }
+            s->num++; s->len_sum += l;
+            if (l < s->len_min) s->len_min = l;
+            if (l > s->len_max) s->len_max = l;
+            s->gap_sum += (int64_t)ora_count_bytes(rec.seq, rec.seq_len, (const uint8_t *)gaps, strlen(gaps));
+        }
+        int ab = ora_reader_alphabet(r);
+        ora_reader_close(r);
+        if (rc < 0) { fprintf(err, "[ERRO] error when parsing %s\n", files[f]); free(lens); free(infos); return 255; }
+        if (ab == ORA_ALPHABET_DNAredundant) strcpy(s->type, "DNA");
+        else if (ab == ORA_ALPHABET_RNAredundant) strcpy(s->type, "RNA");
+        else strcpy(s->type, ora_alphabet_name(ab));
+        if (o->all) {
+            qsort(lens, (size_t)s->num, sizeof *lens, cmp_i64);
+            ora_n50(lens, (size_t)s->num, s->len_sum, &s->n50, &s->l50);
+            ora_quartile(lens, (size_t)s->num, &s->q1, &s->q2, &s->q3);
+        }
+        free(lens);
+        if (s->num == 0) { s->len_sum = s->gap_sum = s->len_min = 0; s->len_avg = 0; s->n50 = s->l50 = 0; }
+        else s->len_avg = ora_round((double)s->len_sum / (double)s->num, 1);
+    }
+    if (o->tabular) {
+        fputs("file\tformat\ttype\tnum_seqs\tsum_len\tmin_len\tavg_len\tmax_len", out);
+        if (o->all) fputs("\tQ1\tQ2\tQ3\tsum_gap\tN50", out);
+        fputc('\n', out);
+        for (int f = 0; f < nfiles; f++) {
+            stat_info *s = &infos[f];
+            fprintf(out, "%s\t%s\t%s\t%lld\t%lld\t%lld\t%.1f\t%lld", s->file, s->format, s->type,
+                    (long long)s->num, (long long)s->len_sum, (long long)s->len_min, s->len_avg,
+                    (long long)s->len_max);
+            if (o->all)
+                fprintf(out, "\t%lld\t%lld\t%lld\t%lld\t%lld", (long long)s->q1, (long long)s->q2,
+                        (long long)s->q3, (long long)s->gap_sum, (long long)s->n50);
+            fputc('\n', out);
+        }
+        free(infos);
+        return 0;
+    }
+    int ncol = o->all ? 13 : 8;
+    static const char *hdr[13] = {"file", "format", "type", "num_seqs", "sum_len", "min_len", "avg_len",
+                                  "max_len", "Q1", "Q2", "Q3", "sum_gap", "N50"};
+    static const int right[13] = {0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
+    int nrow = nfiles + 1;
+    char ***cells = (char ***)calloc((size_t)nrow, sizeof *cells);
+    for (int r = 0; r < nrow; r++) {
+        cells[r] = (char **)calloc((size_t)ncol, sizeof **cells);
+        for (int c = 0; c < ncol; c++) cells[r][c] = (char *)calloc(1, 4352);
+    }
+    for (int c = 0; c < ncol; c++) strcpy(cells[0][c], hdr[c]);
+    for (int f = 0; f < nfiles; f++) {
+        stat_info *s = &infos[f]; char **row = cells[f + 1];
+        snprintf(row[0], 4352, "%s", s->file); strcpy(row[1], s->format); strcpy(row[2], s->type);
+        ora_comma(s->num, row[3]); ora_comma(s->len_sum, row[4]); ora_comma(s->len_min, row[5]);
+        ora_commaf(s->len_avg, row[6]); ora_comma(s->len_max, row[7]);
+        if (o->all) {
+            ora_comma(s->q1, row[8]); ora_comma(s->q2, row[9]); ora_comma(s->q3, row[10]);
+            ora_comma(s->gap_sum, row[11]); ora_comma(s->n50, row[12]);
+        }
+    }
+    pretty_table(out, ncol, right, nrow, cells);
+    for (int r = 0; r < nrow; r++) { for (int c = 0; c < ncol; c++) free(cells[r][c]); free(cells[r]); }
+    free(cells); free(infos);
+    return 0;
+}

@@ -1,0 +1,128 @@
+/*
+ * seqkit_oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Plain-C CPU restatement of SeqKit's per-record hot path (reverse, complement,
+ * base content, gap counting, stats reduction) and of the exact text formatting
+ * the three commands `seq`, `fx2tab`, `stats` wrap around it.  It exists so the
+ * parity tests have something independent to compare the HIP path against.
+ * Nothing in the product (seqkit_amd/, include/) may include, link or execute it;
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do.
+ *
+ * Where the algorithm comes from: the reference tree (sauloalgolang/seqkit,
+ * SeqKit 0.7.2s) only holds the CALL SITES -- seqkit/cmd/seq.go:186-195,
+ * seqkit/cmd/fx2tab.go:124-148, seqkit/cmd/stat.go:96-160.  The arithmetic lives in
+ * Go modules that are neither vendored nor version-pinned in that tree:
+ *   github.com/shenwei356/bio   (seq, seqio/fastx)     -- no go.mod, unpinned
+ *   github.com/shenwei356/util  (byteutil, math)       -- no go.mod, unpinned
+ *   github.com/dustin/go-humanize, github.com/tatsushid/go-prettytable -- unpinned
+ * Their published behaviour is restated here and pinned against every known
+ * answer the reference's own docs and tests hold for this path (see
+ * tests/test_oracle_golden.py, tests/golden/expected/...).  Behaviour that no
+ * in-tree vector covers is marked "parity unpinned" at the function.
+ */
+#ifndef SEQKIT_ORACLE_H
+#define SEQKIT_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Alphabets the fastx reader can hand to a command (bio/seq alphabet.go). */
+enum {
+    ORA_ALPHABET_DNA = 0,
+    ORA_ALPHABET_DNAredundant = 1,
+    ORA_ALPHABET_RNA = 2,
+    ORA_ALPHABET_RNAredundant = 3,
+    ORA_ALPHABET_Protein = 4,
+    ORA_ALPHABET_Unlimit = 5
+};
+
+const char *ora_alphabet_name(int alphabet);
+/* membership table of letters+gap+ambiguous letters of the alphabet */
+void ora_alphabet_members(int alphabet, uint8_t is_member[256]);
+/* PairLetter table; bytes outside the alphabet map to themselves (parity unpinned) */
+void ora_pair_table(int alphabet, uint8_t lut[256]);
+/* GuessAlphabetLessConservatively on the first `threshold` bytes (0 = all) */
+int ora_guess_alphabet(const uint8_t *seq, size_t n, size_t threshold);
+
+/* seq.go:188  (*Seq).ReverseInplace: reverses Seq and, when present, Qual */
+void ora_reverse_inplace(uint8_t *seq, uint8_t *qual, size_t n);
+/* seq.go:194  (*Seq).ComplementInplace */
+void ora_complement_inplace(uint8_t *seq, size_t n, int alphabet);
+/* locate.go:154 / subseq.go:399  RevCom = reverse then complement */
+void ora_revcom_inplace(uint8_t *seq, uint8_t *qual, size_t n, int alphabet);
+
+/* fx2tab.go:128,129,141  (*Seq).BaseContent(list) */
+double ora_base_content(const uint8_t *seq, size_t n, const char *list);
+/* integer numerator of BaseContent (what the GPU path produces) */
+uint64_t ora_base_count(const uint8_t *seq, size_t n, const char *list);
+/* stat.go:125  byteutil.CountBytes */
+uint64_t ora_count_bytes(const uint8_t *seq, size_t n, const uint8_t *letters, size_t nletters);
+
+/* seq.go:244  byteutil.WrapByteSlice; `out` needs n + n/width + 1 bytes; returns length */
+size_t ora_wrap(const uint8_t *s, size_t n, int width, uint8_t *out);
+
+/* stat.go:158  util/math.Round(f, n) */
+double ora_round(double f, int n);
+/* stat.go:297-326 on an ascending-sorted array */
+int64_t ora_median(const int64_t *sorted, size_t l);
+void ora_quartile(const int64_t *sorted, size_t l, int64_t *q1, int64_t *q2, int64_t *q3);
+/* stat.go:136-145 */
+void ora_n50(const int64_t *sorted, size_t num, int64_t len_sum, int64_t *n50, int64_t *l50);
+
+/* go-humanize Comma / Commaf; buf >= 64 bytes */
+void ora_comma(int64_t v, char *buf);
+void ora_commaf(double v, char *buf);
+/* Go's fmt "%.<prec>f" incl. NaN/Inf spelling; buf >= 400 bytes */
+void ora_fmt_fixed(double v, int prec, char *buf);
+
+/* ---- FASTA/Q reader (bio/seqio/fastx restated; plain or gzip input, "-" = stdin) ---- */
+typedef struct ora_record {
+    uint8_t *name; size_t name_len;   /* head line without '>'/'@' */
+    size_t id_len;                    /* ID = name[0..id_len) (default id regexp) */
+    uint8_t *seq;  size_t seq_len;
+    uint8_t *qual; size_t qual_len;   /* 0 for FASTA */
+} ora_record;
+
+typedef struct ora_reader ora_reader;
+ora_reader *ora_reader_open(const char *path, int forced_alphabet /* -1 = guess */,
+                            size_t guess_threshold);
+/* 1 = record returned (valid until next call), 0 = EOF, <0 = parse error */
+int ora_reader_next(ora_reader *r, ora_record *rec);
+int ora_reader_is_fastq(const ora_reader *r);
+int ora_reader_alphabet(const ora_reader *r);   /* -1 until the first record was read */
+void ora_reader_close(ora_reader *r);
+
+/* ---- whole-command restatements; write exactly the bytes the Go command writes ---- */
+typedef struct ora_seq_opts {
+    int reverse, complement;  /* -r -p */
+    int only_name, only_seq, only_qual, only_id; /* -n -s -q -i */
+    int line_width;           /* -w (default 60) */
+    int min_len, max_len;     /* -m -M (-1 = off) */
+    int alphabet;             /* -t: -1 auto */
+    size_t guess_len;         /* --alphabet-guess-seq-length (default 10000) */
+} ora_seq_opts;
+int ora_cmd_seq(const ora_seq_opts *o, int nfiles, const char **files, FILE *out, FILE *err);
+
+typedef struct ora_fx2tab_opts {
+    int only_id, length, gc, gc_skew, only_name, header_line, alphabet_col; /* -i -l -g -G -n -H -a */
+    int nbase; const char **base;  /* -B values in order */
+    size_t guess_len;
+} ora_fx2tab_opts;
+int ora_cmd_fx2tab(const ora_fx2tab_opts *o, int nfiles, const char **files, FILE *out, FILE *err);
+
+typedef struct ora_stats_opts {
+    int all, tabular;           /* -a -T */
+    const char *gap_letters;    /* -G (default "- .") */
+    size_t guess_len;
+} ora_stats_opts;
+int ora_cmd_stats(const ora_stats_opts *o, int nfiles, const char **files, FILE *out, FILE *err);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
