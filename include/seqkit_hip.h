@@ -1,0 +1,161 @@
+/*
+ * seqkit_hip.h -- C ABI of libseqkit_hip.so: SeqKit's per-record hot path
+ * (reverse / complement / base counting / stats totals) on AMD MI355X (gfx950).
+ *
+ * The reference (SeqKit 0.7.2s, Go) has no FFI on this path: its commands call
+ * methods of github.com/shenwei356/bio/seq and shenwei356/util/byteutil once per
+ * record from a serial loop.  This ABI replaces those per-record calls with
+ * per-BATCH calls.  A batch is a CSR pair: all sequence bytes of the batch back to
+ * back in `seq` (no separators, no line breaks), and `offsets[nrec+1]` (uint64,
+ * offsets[0] = 0, non-decreasing) such that record r is seq[offsets[r]..offsets[r+1]).
+ * FASTQ qualities live in a second byte buffer that shares the same offsets.
+ *
+ * Conventions
+ *  - every function returns 0 on success or a negative SKH_E* code; a message for
+ *    the calling thread is available from skh_last_error();
+ *  - no function throws, aborts, or calls exit(); nothing is printed;
+ *  - tables (complement LUT, class table) are host memory, read during the call;
+ *  - one context drives one GPU; use one process (or one context) per GPU;
+ *  - the *_dev entry points take DEVICE pointers and enqueue on `stream`
+ *    (a hipStream_t passed as void*, NULL = the context's own stream) without
+ *    synchronising; the batch entry points are synchronous.
+ *  - device buffers handed to *_dev functions must be 16-byte aligned and readable
+ *    (inputs) / writable (outputs) up to skh_padded_size(total_bytes).
+ */
+#ifndef SEQKIT_HIP_H
+#define SEQKIT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SKH_OK           0
+#define SKH_EINVAL      -1   /* bad argument (NULL pointer, nclass out of range, ...) */
+#define SKH_ENODEV      -2   /* no usable gfx950 device / device ordinal out of range */
+#define SKH_ENOMEM      -3   /* host or device allocation failed */
+#define SKH_EHIP        -4   /* a HIP runtime call failed; see skh_last_error() */
+#define SKH_ECAPACITY   -5   /* batch larger than its allocated capacity */
+
+#define SKH_MAX_CLASSES  8   /* classes per counting pass */
+#define SKH_NO_CLASS  0xFF   /* class_of[] value for "do not count this byte" */
+
+typedef struct skh_ctx skh_ctx;
+typedef struct skh_batch skh_batch;
+
+/* Per-file totals of `seqkit stats` (replaces the accumulators of
+ * seqkit/cmd/stat.go:78,91,106-125).  len_min is INT64_MAX and len_max 0 for
+ * an empty batch, exactly like the Go initial values (stat.go:91). */
+typedef struct skh_stats_partial {
+    int64_t num;       /* records                      (stat.go:106) */
+    int64_t len_sum;   /* sum of lengths               (stat.go:118) */
+    int64_t gap_sum;   /* bytes that are gap letters   (stat.go:125) */
+    int64_t len_min;   /*                              (stat.go:119-121) */
+    int64_t len_max;   /*                              (stat.go:122-124) */
+} skh_stats_partial;
+
+/* Message describing the calling thread's most recent failure ("" if none). */
+const char *skh_last_error(void);
+/* Library version string, e.g. "seqkit-hip 0.1 gfx950". */
+const char *skh_version(void);
+/* Bytes a device/pinned sequence buffer must span for `total_bytes` of sequence. */
+uint64_t skh_padded_size(uint64_t total_bytes);
+
+/* Creates a context on HIP device `device` (ordinal as seen by this process). */
+int skh_init(int device, skh_ctx **out);
+void skh_destroy(skh_ctx *ctx);
+/* Blocks until everything enqueued on the context's own stream has finished. */
+int skh_sync(skh_ctx *ctx);
+
+/* ---- table builders (host only; replace bio/seq alphabet lookups) ------------------
+ * skh_pair_table: the PairLetter table ComplementInplace applies
+ * (call site seqkit/cmd/seq.go:194; alphabet chosen at seqkit/cmd/helper.go:138-156
+ * or guessed by the reader).  alphabet: 0 DNA, 1 DNAredundant, 2 RNA, 3 RNAredundant,
+ * 4 Protein, 5 Unlimit.  Bytes outside the alphabet map to themselves. */
+int skh_pair_table(int alphabet, uint8_t lut[256]);
+/* skh_class_table: class table for (*Seq).BaseContent(list) letters
+ * (seqkit/cmd/fx2tab.go:128-141): for each i < nlists, every letter of lists[i] in
+ * either case maps to class i.  Fails with SKH_EINVAL if two lists share a letter
+ * (the caller must then use separate passes) or nlists > SKH_MAX_CLASSES. */
+int skh_class_table(const char *const *lists, uint32_t nlists, uint8_t class_of[256]);
+
+/* ---- device-resident entry points -------------------------------------------------- */
+
+/* Reverse and/or complement every record of a batch, out of place.
+ * Replaces (*Seq).ReverseInplace / ComplementInplace / RevCom
+ * (call sites seqkit/cmd/seq.go:187-195, locate.go:154, subseq.go:399,491).
+ *   d_out[offsets[r] + L-1-j] = lut[d_in[offsets[r] + j]]   (do_reverse)
+ *   d_out[offsets[r] + j]     = lut[d_in[offsets[r] + j]]   (!do_reverse)
+ * lut == NULL means identity (quality strings: reverse only).  d_in and d_out must
+ * not overlap.  Bytes of d_out at and beyond total_bytes are not written. */
+int skh_revcomp_dev(skh_ctx *ctx, const uint8_t *d_in, uint8_t *d_out,
+                    const uint64_t *d_offsets, uint64_t nrec, uint64_t total_bytes,
+                    const uint8_t *lut, int do_reverse, void *stream);
+
+/* FASTQ form of the above in one pass: bases are reversed (if do_reverse) and mapped
+ * through lut, qualities are reversed (if do_reverse) and otherwise copied
+ * (seq.go:188 reverses Seq and Qual together; seq.go:194 touches Seq only). */
+int skh_revcomp_fastq_dev(skh_ctx *ctx, const uint8_t *d_seq_in, uint8_t *d_seq_out,
+                          const uint8_t *d_qual_in, uint8_t *d_qual_out,
+                          const uint64_t *d_offsets, uint64_t nrec, uint64_t total_bytes,
+                          const uint8_t *lut, int do_reverse, void *stream);
+
+/* Per-record byte-class histogram.  Replaces the bytes.Count scans inside
+ * (*Seq).BaseContent (call sites seqkit/cmd/fx2tab.go:128,129,141) and
+ * byteutil.CountBytes (seqkit/cmd/stat.go:125) by one pass:
+ *   d_counts[r*nclass + c] = #{ j : class_of[seq[offsets[r]+j]] == c },  c < nclass.
+ * class_of[b] is a class index < nclass or SKH_NO_CLASS.  1 <= nclass <= SKH_MAX_CLASSES. */
+int skh_count_dev(skh_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_offsets,
+                  uint64_t nrec, uint64_t total_bytes, const uint8_t class_of[256],
+                  uint32_t nclass, uint64_t *d_counts, void *stream);
+
+/* Whole-batch totals for `stats` (accumulators of seqkit/cmd/stat.go:106-125):
+ * writes one skh_stats_partial to DEVICE memory d_out. */
+int skh_stats_dev(skh_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_offsets,
+                  uint64_t nrec, uint64_t total_bytes, const uint8_t is_gap[256],
+                  skh_stats_partial *d_out, void *stream);
+
+/* ---- pinned-host batches (what a cgo / C++ reader fills) ---------------------------- */
+
+/* Allocates pinned host staging plus matching device buffers for up to max_bytes of
+ * sequence and max_records records (with_qual != 0 adds the quality plane). */
+int skh_batch_alloc(skh_ctx *ctx, uint64_t max_bytes, uint64_t max_records, int with_qual,
+                    skh_batch **out);
+void skh_batch_free(skh_batch *b);
+uint8_t  *skh_batch_seq(skh_batch *b);       /* max_bytes (padded) bytes            */
+uint8_t  *skh_batch_qual(skh_batch *b);      /* NULL when allocated without quality */
+uint64_t *skh_batch_offsets(skh_batch *b);   /* max_records + 1 entries             */
+uint64_t  skh_batch_max_bytes(const skh_batch *b);
+uint64_t  skh_batch_max_records(const skh_batch *b);
+
+/* In place on the batch (host view): upload, transform on the GPU, download.
+ * lut NULL = no complement; reverse_qual reverses the quality plane too
+ * (ignored when the batch has none). */
+int skh_revcomp(skh_ctx *ctx, skh_batch *b, uint64_t nrec, const uint8_t *lut,
+                int do_reverse, int reverse_qual);
+/* counts: host array of nrec*nclass uint64, row-major by record. */
+int skh_count(skh_ctx *ctx, skh_batch *b, uint64_t nrec, const uint8_t class_of[256],
+              uint32_t nclass, uint64_t *counts);
+/* Adds this batch's totals into *inout (sum for num/len_sum/gap_sum, min/max for the
+ * extremes); initialise *inout with skh_stats_init before the first batch of a file. */
+void skh_stats_init(skh_stats_partial *p);
+int skh_stats_reduce(skh_ctx *ctx, skh_batch *b, uint64_t nrec, const uint8_t is_gap[256],
+                     skh_stats_partial *inout);
+/* Merge rule for per-GPU partials (what an all-reduce applies element-wise). */
+void skh_stats_merge(skh_stats_partial *into, const skh_stats_partial *from);
+
+/* Split-phase forms for overlap: skh_*_submit enqueue upload + kernels + download on the
+ * batch's own stream and return; skh_batch_wait blocks until that batch is done.  Two
+ * batches submitted back to back overlap one's transfers with the other's kernels. */
+int skh_revcomp_submit(skh_ctx *ctx, skh_batch *b, uint64_t nrec, const uint8_t *lut,
+                       int do_reverse, int reverse_qual);
+int skh_count_submit(skh_ctx *ctx, skh_batch *b, uint64_t nrec, const uint8_t class_of[256],
+                     uint32_t nclass, uint64_t *counts);
+int skh_batch_wait(skh_batch *b);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

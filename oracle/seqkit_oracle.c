@@ -144,6 +144,46 @@ uint64_t ora_count_bytes(const uint8_t *seq, size_t n, const uint8_t *letters, s
     return c;
 }
 
+/* ------------------------------------------------------------------ CSR batches */
+/* One record at a time, exactly as the Go loops do (seq.go:119-195, fx2tab.go:98-143,
+ * stat.go:96-126); the batch is only the container. */
+void ora_batch_transform(uint8_t *seq, uint8_t *qual, const uint64_t *offs, uint64_t nrec,
+                         const uint8_t *lut, int do_reverse)
+{
+    for (uint64_t r = 0; r < nrec; r++) {
+        uint8_t *s = seq + offs[r]; size_t n = (size_t)(offs[r + 1] - offs[r]);
+        if (do_reverse) ora_reverse_inplace(s, qual ? qual + offs[r] : NULL, n);
+        if (lut) for (size_t i = 0; i < n; i++) s[i] = lut[s[i]];
+    }
+}
+
+void ora_batch_count(const uint8_t *seq, const uint64_t *offs, uint64_t nrec,
+                     const uint8_t class_of[256], uint32_t nclass, uint64_t *counts)
+{
+    for (uint64_t r = 0; r < nrec; r++) {
+        uint64_t *row = counts + r * nclass;
+        for (uint32_t c = 0; c < nclass; c++) row[c] = 0;
+        for (uint64_t i = offs[r]; i < offs[r + 1]; i++) {
+            uint8_t c = class_of[seq[i]];
+            if (c < nclass) row[c]++;
+        }
+    }
+}
+
+void ora_batch_stats(const uint8_t *seq, const uint64_t *offs, uint64_t nrec,
+                     const uint8_t *gap_letters, size_t ngap, int64_t out[5])
+{
+    int64_t num = 0, len_sum = 0, gap_sum = 0, len_min = INT64_MAX, len_max = 0;
+    for (uint64_t r = 0; r < nrec; r++) {
+        int64_t l = (int64_t)(offs[r + 1] - offs[r]);
+        num++; len_sum += l;
+        if (l < len_min) len_min = l;
+        if (l > len_max) len_max = l;
+        gap_sum += (int64_t)ora_count_bytes(seq + offs[r], (size_t)l, gap_letters, ngap);
+    }
+    out[0] = num; out[1] = len_sum; out[2] = gap_sum; out[3] = len_min; out[4] = len_max;
+}
+
 /* ------------------------------------------------------------------ formatting */
 /* seqkit/cmd/seq.go:243-253 -> byteutil.WrapByteSlice: '\n' after every `width`
  * bytes except after the last line (tests/test.sh:22-26 pins len%width==0). */

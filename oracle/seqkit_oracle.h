@@ -80,6 +80,18 @@ void ora_commaf(double v, char *buf);
 /* Go's fmt "%.<prec>f" incl. NaN/Inf spelling; buf >= 400 bytes */
 void ora_fmt_fixed(double v, int prec, char *buf);
 
+/* ---- the same per-record functions looped over a CSR batch (seq bytes back to back,
+ * offs[nrec+1]); what the GPU entry points are compared with ---- */
+/* lut NULL = no complement; qual NULL = no quality plane; in place */
+void ora_batch_transform(uint8_t *seq, uint8_t *qual, const uint64_t *offs, uint64_t nrec,
+                         const uint8_t *lut, int do_reverse);
+/* counts[r*nclass+c] = bytes of record r whose class_of[] is c (0xFF = none) */
+void ora_batch_count(const uint8_t *seq, const uint64_t *offs, uint64_t nrec,
+                     const uint8_t class_of[256], uint32_t nclass, uint64_t *counts);
+/* out = {num, len_sum, gap_sum, len_min, len_max} with the stat.go:91 initial values */
+void ora_batch_stats(const uint8_t *seq, const uint64_t *offs, uint64_t nrec,
+                     const uint8_t *gap_letters, size_t ngap, int64_t out[5]);
+
 /* ---- FASTA/Q reader (bio/seqio/fastx restated; plain or gzip input, "-" = stdin) ---- */
 typedef struct ora_record {
     uint8_t *name; size_t name_len;   /* head line without '>'/'@' */

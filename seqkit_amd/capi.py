@@ -1,0 +1,108 @@
+"""ctypes binding of include/seqkit_hip.h (one-to-one, no logic of its own)."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libseqkit_hip.so")
+
+MAX_CLASSES = 8
+NO_CLASS = 0xFF
+
+# every symbol declared in include/seqkit_hip.h: name -> (restype, argtypes)
+u8p, u64p, vp = C.POINTER(C.c_uint8), C.POINTER(C.c_uint64), C.c_void_p
+
+
+class StatsPartial(C.Structure):
+    _fields_ = [("num", C.c_int64), ("len_sum", C.c_int64), ("gap_sum", C.c_int64),
+                ("len_min", C.c_int64), ("len_max", C.c_int64)]
+
+    def as_tuple(self):
+        return (self.num, self.len_sum, self.gap_sum, self.len_min, self.len_max)
+
+
+SYMBOLS = {
+    "skh_last_error": (C.c_char_p, []),
+    "skh_version": (C.c_char_p, []),
+    "skh_padded_size": (C.c_uint64, [C.c_uint64]),
+    "skh_init": (C.c_int, [C.c_int, C.POINTER(vp)]),
+    "skh_destroy": (None, [vp]),
+    "skh_sync": (C.c_int, [vp]),
+    "skh_pair_table": (C.c_int, [C.c_int, u8p]),
+    "skh_class_table": (C.c_int, [C.POINTER(C.c_char_p), C.c_uint32, u8p]),
+    "skh_revcomp_dev": (C.c_int, [vp, vp, vp, vp, C.c_uint64, C.c_uint64, u8p, C.c_int, vp]),
+    "skh_revcomp_fastq_dev": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_uint64, C.c_uint64, u8p, C.c_int, vp]),
+    "skh_count_dev": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_uint64, u8p, C.c_uint32, vp, vp]),
+    "skh_stats_dev": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_uint64, u8p, vp, vp]),
+    "skh_batch_alloc": (C.c_int, [vp, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(vp)]),
+    "skh_batch_free": (None, [vp]),
+    "skh_batch_seq": (vp, [vp]),
+    "skh_batch_qual": (vp, [vp]),
+    "skh_batch_offsets": (vp, [vp]),
+    "skh_batch_max_bytes": (C.c_uint64, [vp]),
+    "skh_batch_max_records": (C.c_uint64, [vp]),
+    "skh_revcomp": (C.c_int, [vp, vp, C.c_uint64, u8p, C.c_int, C.c_int]),
+    "skh_count": (C.c_int, [vp, vp, C.c_uint64, u8p, C.c_uint32, u64p]),
+    "skh_stats_init": (None, [C.POINTER(StatsPartial)]),
+    "skh_stats_reduce": (C.c_int, [vp, vp, C.c_uint64, u8p, C.POINTER(StatsPartial)]),
+    "skh_stats_merge": (None, [C.POINTER(StatsPartial), C.POINTER(StatsPartial)]),
+    "skh_revcomp_submit": (C.c_int, [vp, vp, C.c_uint64, u8p, C.c_int, C.c_int]),
+    "skh_count_submit": (C.c_int, [vp, vp, C.c_uint64, u8p, C.c_uint32, u64p]),
+    "skh_batch_wait": (C.c_int, [vp]),
+}
+
+
+class SkhError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("seqkit_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Lib:
+    """The loaded library with typed entry points; `check` raises on a negative return."""
+
+    def __init__(self, path=LIB_PATH):
+        if not os.path.exists(path):
+            raise ImportError("%s is missing: build it with `python seqkit_amd/build.py` "
+                              "(there is no CPU fallback)" % path)
+        self.dll = C.CDLL(path)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(self.dll, name)      # AttributeError if the library lacks a declared symbol
+            fn.restype, fn.argtypes = res, args
+            setattr(self, name, fn)
+
+    def check(self, rc):
+        if rc != 0:
+            raise SkhError(rc, self.skh_last_error().decode())
+        return rc
+
+    # small conveniences used by tests/bench (argument marshalling only)
+    @staticmethod
+    def table(values):
+        arr = (C.c_uint8 * 256)(*values)
+        return arr
+
+    def pair_table(self, alphabet):
+        t = (C.c_uint8 * 256)()
+        self.check(self.skh_pair_table(alphabet, t))
+        return t
+
+    def class_table(self, lists):
+        arr = (C.c_char_p * len(lists))(*[s.encode() if isinstance(s, str) else s for s in lists])
+        t = (C.c_uint8 * 256)()
+        self.check(self.skh_class_table(arr, len(lists), t))
+        return t
+
+    def init(self, device=0):
+        ctx = vp()
+        self.check(self.skh_init(device, C.byref(ctx)))
+        return ctx
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is None:
+        _lib = Lib()
+    return _lib

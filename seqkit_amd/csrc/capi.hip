@@ -1,0 +1,503 @@
+// capi.hip -- the extern "C" surface of libseqkit_hip.so (see include/seqkit_hip.h).
+//
+// Host-side only: argument checks, table building, stream/buffer ownership and the
+// launches declared in kernels.h.  No torch types, no exceptions across the ABI.
+#include "seqkit_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, const char* a = "", const char* b = "")
+{
+    char buf[512];
+    snprintf(buf, sizeof buf, fmt, a, b);
+    g_err = buf;
+    return code;
+}
+
+int hip_fail(hipError_t e, const char* what)
+{
+    return fail(e == hipErrorOutOfMemory ? SKH_ENOMEM : SKH_EHIP, "%s: %s", what, hipGetErrorString(e));
+}
+
+#define HIP_TRY(expr)                                           \
+    do {                                                        \
+        hipError_t e_ = (expr);                                 \
+        if (e_ != hipSuccess) return hip_fail(e_, #expr);       \
+    } while (0)
+
+constexpr int N_FLAGS = 64;
+
+int env_int(const char* name, int dflt)
+{
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
+}  // namespace
+
+struct skh_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    uint32_t* d_flags = nullptr;           // ring of "long records seen" words
+    std::atomic<uint32_t> flag_next{0};
+    uint32_t max_grid = 2048;
+    int force_logG = -1;
+};
+
+struct skh_batch {
+    skh_ctx* ctx = nullptr;
+    uint64_t max_bytes = 0, max_records = 0;
+    bool with_qual = false;
+    uint8_t *h_seq = nullptr, *h_qual = nullptr;
+    uint64_t* h_offs = nullptr;
+    uint8_t *d_seq = nullptr, *d_seq_out = nullptr, *d_qual = nullptr, *d_qual_out = nullptr;
+    uint64_t* d_offs = nullptr;
+    uint64_t *d_counts = nullptr, *h_counts = nullptr;
+    skh::StatsPartial *d_stats = nullptr, *h_stats = nullptr;
+    hipStream_t stream = nullptr;
+    // completion of a submitted operation
+    uint64_t* user_counts = nullptr;
+    uint64_t n_counts = 0;
+    bool pending = false;
+};
+
+namespace {
+
+skh::LaunchCfg cfg_for(const skh_ctx* ctx, uint64_t nrec, uint64_t total)
+{
+    skh::LaunchCfg c;
+    c.max_grid = ctx->max_grid;
+    if (ctx->force_logG >= 0) {
+        c.logG = ctx->force_logG > 6 ? 6 : ctx->force_logG;
+        return c;
+    }
+    // about three 16-byte chunks per lane: 150-base reads -> 4 lanes per record
+    const uint64_t mean = nrec ? total / nrec : 0;
+    const uint64_t chunks = (mean + 15) / 16 + 1;
+    const uint64_t lanes = (chunks + 2) / 3;
+    int lg = 0;
+    while (lg < 6 && (1ull << lg) < lanes) lg++;
+    c.logG = lg;
+    return c;
+}
+
+uint32_t* next_flag(skh_ctx* ctx)
+{
+    return ctx->d_flags + (ctx->flag_next.fetch_add(1) % N_FLAGS);
+}
+
+int check_plane_args(const void* a, const void* offs, uint64_t nrec, uint64_t total)
+{
+    if (nrec != 0 && offs == nullptr) return fail(SKH_EINVAL, "offsets pointer is NULL");
+    if (total != 0 && a == nullptr) return fail(SKH_EINVAL, "sequence pointer is NULL");
+    if (reinterpret_cast<uintptr_t>(a) & 15) return fail(SKH_EINVAL, "sequence plane is not 16-byte aligned");
+    if (total != 0 && nrec == 0) return fail(SKH_EINVAL, "total_bytes > 0 with zero records");
+    return SKH_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* skh_last_error(void) { return g_err.c_str(); }
+const char* skh_version(void) { return "seqkit-hip 0.1 gfx950"; }
+uint64_t skh_padded_size(uint64_t total_bytes) { return (total_bytes + 15) & ~15ull; }
+
+int skh_init(int device, skh_ctx** out)
+{
+    if (!out) return fail(SKH_EINVAL, "skh_init: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return fail(SKH_ENODEV, "no HIP device visible (%s)", hipGetErrorString(e));
+    if (device < 0 || device >= n) return fail(SKH_ENODEV, "device ordinal out of range");
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    skh_ctx* c = new (std::nothrow) skh_ctx;
+    if (!c) return fail(SKH_ENOMEM, "out of host memory");
+    c->device = device;
+    c->max_grid = (uint32_t)env_int("SKH_MAX_GRID", prop.multiProcessorCount * 8);
+    if (c->max_grid < 1) c->max_grid = 1;
+    c->force_logG = env_int("SKH_LOGG", -1);
+    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->d_flags), N_FLAGS * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemset(c->d_flags, 0, N_FLAGS * sizeof(uint32_t));
+    if (e != hipSuccess) {
+        skh_destroy(c);
+        return hip_fail(e, "skh_init");
+    }
+    *out = c;
+    return SKH_OK;
+}
+
+void skh_destroy(skh_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+    if (c->d_flags) (void)hipFree(c->d_flags);
+    delete c;
+}
+
+int skh_sync(skh_ctx* c)
+{
+    if (!c) return fail(SKH_EINVAL, "ctx is NULL");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SKH_OK;
+}
+
+// ---------------------------------------------------------------- tables
+
+int skh_pair_table(int alphabet, uint8_t lut[256])
+{
+    // PairLetter tables of the reader's alphabets (bio/seq alphabet.go): letters map
+    // to their pairs, gap (" -.") and ambiguous ("nN.") letters and every byte
+    // outside the alphabet to themselves.  Protein pairs are the letters themselves
+    // and Unlimit has no table, so both are the identity.
+    if (!lut) return fail(SKH_EINVAL, "lut is NULL");
+    for (int i = 0; i < 256; i++) lut[i] = (uint8_t)i;
+    const char *from = "", *to = "";
+    switch (alphabet) {
+        case 0: from = "acgtACGT"; to = "tgcaTGCA"; break;
+        case 1: from = "acgtryswkmbdhvACGTRYSWKMBDHV"; to = "tgcayrswmkvhdbTGCAYRSWMKVHDB"; break;
+        case 2: from = "acguACGU"; to = "ugcaUGCA"; break;
+        case 3: from = "acguryswkmbdhvACGURYSWKMBDHV"; to = "ugcayrswmkvhdbUGCAYRSWMKVHDB"; break;
+        case 4: case 5: break;
+        default: return fail(SKH_EINVAL, "unknown alphabet id");
+    }
+    for (size_t i = 0; from[i]; i++) lut[(uint8_t)from[i]] = (uint8_t)to[i];
+    return SKH_OK;
+}
+
+int skh_class_table(const char* const* lists, uint32_t nlists, uint8_t class_of[256])
+{
+    if (!class_of || (nlists && !lists)) return fail(SKH_EINVAL, "NULL argument");
+    if (nlists > SKH_MAX_CLASSES) return fail(SKH_EINVAL, "more than SKH_MAX_CLASSES lists");
+    memset(class_of, SKH_NO_CLASS, 256);
+    for (uint32_t i = 0; i < nlists; i++) {
+        if (!lists[i]) return fail(SKH_EINVAL, "NULL list");
+        for (const char* p = lists[i]; *p; p++) {
+            uint8_t b = (uint8_t)*p, up = b, lo = b;
+            if (b >= 'a' && b <= 'z') up = (uint8_t)(b - 32);
+            if (b >= 'A' && b <= 'Z') lo = (uint8_t)(b + 32);
+            const uint8_t both[2] = {up, lo};
+            for (int k = 0; k < 2; k++) {
+                if (class_of[both[k]] != SKH_NO_CLASS && class_of[both[k]] != i)
+                    return fail(SKH_EINVAL, "a letter appears in two class lists");
+                class_of[both[k]] = (uint8_t)i;
+            }
+        }
+    }
+    return SKH_OK;
+}
+
+// ---------------------------------------------------------------- device entry points
+
+static int revcomp_impl(skh_ctx* ctx, const uint8_t* d_in, uint8_t* d_out, const uint8_t* d_qin,
+                        uint8_t* d_qout, const uint64_t* d_offs, uint64_t nrec, uint64_t total,
+                        const uint8_t* lut, int do_reverse, hipStream_t st)
+{
+    if (!ctx) return fail(SKH_EINVAL, "ctx is NULL");
+    int rc = check_plane_args(d_in, d_offs, nrec, total);
+    if (rc) return rc;
+    if (total != 0 && !d_out) return fail(SKH_EINVAL, "output pointer is NULL");
+    if (reinterpret_cast<uintptr_t>(d_out) & 15) return fail(SKH_EINVAL, "output plane is not 16-byte aligned");
+    if ((d_qin == nullptr) != (d_qout == nullptr)) return fail(SKH_EINVAL, "quality in/out must both be given");
+    if ((reinterpret_cast<uintptr_t>(d_qin) | reinterpret_cast<uintptr_t>(d_qout)) & 15)
+        return fail(SKH_EINVAL, "quality plane is not 16-byte aligned");
+    if (total == 0) return SKH_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    skh::Table256 t;
+    if (lut) memcpy(t.v, lut, 256);
+    const skh::LaunchCfg cfg = cfg_for(ctx, nrec, total);
+    if (do_reverse) {
+        uint32_t* flag = next_flag(ctx);
+        HIP_TRY(hipMemsetAsync(flag, 0, sizeof(uint32_t), st));
+        HIP_TRY(skh::launch_reverse(cfg, d_in, d_out, d_qin, d_qout, d_offs, nrec, total,
+                                    lut ? &t : nullptr, flag, st));
+    } else {
+        if (lut) HIP_TRY(skh::launch_map_plane(cfg, d_in, d_out, total, t, st));
+        else HIP_TRY(hipMemcpyAsync(d_out, d_in, total, hipMemcpyDeviceToDevice, st));
+        if (d_qin) HIP_TRY(hipMemcpyAsync(d_qout, d_qin, total, hipMemcpyDeviceToDevice, st));
+    }
+    return SKH_OK;
+}
+
+int skh_revcomp_dev(skh_ctx* ctx, const uint8_t* d_in, uint8_t* d_out, const uint64_t* d_offsets,
+                    uint64_t nrec, uint64_t total_bytes, const uint8_t* lut, int do_reverse, void* stream)
+{
+    hipStream_t st = stream ? (hipStream_t)stream : (ctx ? ctx->stream : nullptr);
+    return revcomp_impl(ctx, d_in, d_out, nullptr, nullptr, d_offsets, nrec, total_bytes, lut, do_reverse, st);
+}
+
+int skh_revcomp_fastq_dev(skh_ctx* ctx, const uint8_t* d_seq_in, uint8_t* d_seq_out,
+                          const uint8_t* d_qual_in, uint8_t* d_qual_out, const uint64_t* d_offsets,
+                          uint64_t nrec, uint64_t total_bytes, const uint8_t* lut, int do_reverse,
+                          void* stream)
+{
+    if (total_bytes != 0 && (!d_qual_in || !d_qual_out)) return fail(SKH_EINVAL, "quality pointer is NULL");
+    hipStream_t st = stream ? (hipStream_t)stream : (ctx ? ctx->stream : nullptr);
+    return revcomp_impl(ctx, d_seq_in, d_seq_out, d_qual_in, d_qual_out, d_offsets, nrec, total_bytes, lut,
+                        do_reverse, st);
+}
+
+int skh_count_dev(skh_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_offsets, uint64_t nrec,
+                  uint64_t total_bytes, const uint8_t class_of[256], uint32_t nclass, uint64_t* d_counts,
+                  void* stream)
+{
+    if (!ctx) return fail(SKH_EINVAL, "ctx is NULL");
+    if (!class_of) return fail(SKH_EINVAL, "class_of is NULL");
+    if (nclass < 1 || nclass > SKH_MAX_CLASSES) return fail(SKH_EINVAL, "nclass must be 1..SKH_MAX_CLASSES");
+    int rc = check_plane_args(d_seq, d_offsets, nrec, total_bytes);
+    if (rc) return rc;
+    if (nrec == 0) return SKH_OK;
+    if (!d_counts) return fail(SKH_EINVAL, "counts pointer is NULL");
+    skh::Table256 t;
+    uint32_t neutral = 256;
+    for (int b = 0; b < 256; b++) {
+        const uint8_t c = class_of[b];
+        if (c != SKH_NO_CLASS && c >= nclass) return fail(SKH_EINVAL, "class_of holds a class >= nclass");
+        t.v[b] = c;
+        if (c == SKH_NO_CLASS && neutral == 256) neutral = (uint32_t)b;
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    uint32_t* flag = next_flag(ctx);
+    HIP_TRY(hipMemsetAsync(flag, 0, sizeof(uint32_t), st));
+    HIP_TRY(skh::launch_count(cfg_for(ctx, nrec, total_bytes), d_seq, d_offsets, nrec, total_bytes, t, nclass,
+                              neutral, d_counts, flag, st));
+    return SKH_OK;
+}
+
+int skh_stats_dev(skh_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_offsets, uint64_t nrec,
+                  uint64_t total_bytes, const uint8_t is_gap[256], skh_stats_partial* d_out, void* stream)
+{
+    static_assert(sizeof(skh_stats_partial) == sizeof(skh::StatsPartial), "layout");
+    if (!ctx) return fail(SKH_EINVAL, "ctx is NULL");
+    if (!is_gap || !d_out) return fail(SKH_EINVAL, "NULL argument");
+    int rc = check_plane_args(d_seq, d_offsets, nrec, total_bytes);
+    if (rc) return rc;
+    skh::Table256 t;
+    memcpy(t.v, is_gap, 256);
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    HIP_TRY(skh::launch_stats(cfg_for(ctx, nrec, total_bytes), d_seq, d_offsets, nrec, total_bytes, t,
+                              reinterpret_cast<skh::StatsPartial*>(d_out), st));
+    return SKH_OK;
+}
+
+// ---------------------------------------------------------------- pinned batches
+
+int skh_batch_alloc(skh_ctx* ctx, uint64_t max_bytes, uint64_t max_records, int with_qual, skh_batch** out)
+{
+    if (!ctx || !out) return fail(SKH_EINVAL, "NULL argument");
+    *out = nullptr;
+    HIP_TRY(hipSetDevice(ctx->device));
+    skh_batch* b = new (std::nothrow) skh_batch;
+    if (!b) return fail(SKH_ENOMEM, "out of host memory");
+    b->ctx = ctx;
+    b->max_bytes = skh_padded_size(max_bytes ? max_bytes : 16);
+    b->max_records = max_records ? max_records : 1;
+    b->with_qual = with_qual != 0;
+    const size_t offs_bytes = (b->max_records + 1) * sizeof(uint64_t);
+    hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&b->h_seq), b->max_bytes, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&b->h_offs), offs_bytes, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&b->h_stats), sizeof(skh::StatsPartial), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&b->d_seq), b->max_bytes);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&b->d_seq_out), b->max_bytes);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&b->d_offs), offs_bytes);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&b->d_stats), sizeof(skh::StatsPartial));
+    if (e == hipSuccess && b->with_qual) {
+        e = hipHostMalloc(reinterpret_cast<void**>(&b->h_qual), b->max_bytes, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&b->d_qual), b->max_bytes);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&b->d_qual_out), b->max_bytes);
+    }
+    if (e != hipSuccess) {
+        skh_batch_free(b);
+        return hip_fail(e, "skh_batch_alloc");
+    }
+    b->h_offs[0] = 0;
+    *out = b;
+    return SKH_OK;
+}
+
+void skh_batch_free(skh_batch* b)
+{
+    if (!b) return;
+    (void)hipSetDevice(b->ctx->device);
+    if (b->stream) { (void)hipStreamSynchronize(b->stream); (void)hipStreamDestroy(b->stream); }
+    if (b->h_seq) (void)hipHostFree(b->h_seq);
+    if (b->h_qual) (void)hipHostFree(b->h_qual);
+    if (b->h_offs) (void)hipHostFree(b->h_offs);
+    if (b->h_counts) (void)hipHostFree(b->h_counts);
+    if (b->h_stats) (void)hipHostFree(b->h_stats);
+    if (b->d_seq) (void)hipFree(b->d_seq);
+    if (b->d_seq_out) (void)hipFree(b->d_seq_out);
+    if (b->d_qual) (void)hipFree(b->d_qual);
+    if (b->d_qual_out) (void)hipFree(b->d_qual_out);
+    if (b->d_offs) (void)hipFree(b->d_offs);
+    if (b->d_counts) (void)hipFree(b->d_counts);
+    if (b->d_stats) (void)hipFree(b->d_stats);
+    delete b;
+}
+
+uint8_t* skh_batch_seq(skh_batch* b) { return b ? b->h_seq : nullptr; }
+uint8_t* skh_batch_qual(skh_batch* b) { return b ? b->h_qual : nullptr; }
+uint64_t* skh_batch_offsets(skh_batch* b) { return b ? b->h_offs : nullptr; }
+uint64_t skh_batch_max_bytes(const skh_batch* b) { return b ? b->max_bytes : 0; }
+uint64_t skh_batch_max_records(const skh_batch* b) { return b ? b->max_records : 0; }
+
+// checks the host-side CSR and returns the batch's byte total
+static int batch_total(const skh_batch* b, uint64_t nrec, uint64_t* total)
+{
+    if (!b) return fail(SKH_EINVAL, "batch is NULL");
+    if (b->pending) return fail(SKH_EINVAL, "batch has an unfinished submit; call skh_batch_wait first");
+    if (nrec > b->max_records) return fail(SKH_ECAPACITY, "more records than the batch was allocated for");
+    if (b->h_offs[0] != 0) return fail(SKH_EINVAL, "offsets[0] must be 0");
+    const uint64_t t = b->h_offs[nrec];
+    if (t > b->max_bytes) return fail(SKH_ECAPACITY, "more sequence bytes than the batch was allocated for");
+    *total = t;
+    return SKH_OK;
+}
+
+static int upload(skh_batch* b, uint64_t nrec, uint64_t total, bool qual)
+{
+    HIP_TRY(hipSetDevice(b->ctx->device));
+    HIP_TRY(hipMemcpyAsync(b->d_offs, b->h_offs, (nrec + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, b->stream));
+    const uint64_t padded = skh_padded_size(total);
+    if (padded) HIP_TRY(hipMemcpyAsync(b->d_seq, b->h_seq, padded, hipMemcpyHostToDevice, b->stream));
+    if (qual && padded) HIP_TRY(hipMemcpyAsync(b->d_qual, b->h_qual, padded, hipMemcpyHostToDevice, b->stream));
+    return SKH_OK;
+}
+
+int skh_revcomp_submit(skh_ctx* ctx, skh_batch* b, uint64_t nrec, const uint8_t* lut, int do_reverse,
+                       int reverse_qual)
+{
+    if (!ctx) return fail(SKH_EINVAL, "ctx is NULL");
+    uint64_t total = 0;
+    int rc = batch_total(b, nrec, &total);
+    if (rc) return rc;
+    if (b->ctx != ctx) return fail(SKH_EINVAL, "batch belongs to another context");
+    if (total == 0 || (!lut && !do_reverse)) return SKH_OK;
+    const bool qual = b->with_qual && reverse_qual && do_reverse;
+    rc = upload(b, nrec, total, qual);
+    if (rc) return rc;
+    rc = revcomp_impl(ctx, b->d_seq, b->d_seq_out, qual ? b->d_qual : nullptr, qual ? b->d_qual_out : nullptr,
+                      b->d_offs, nrec, total, lut, do_reverse, b->stream);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(b->h_seq, b->d_seq_out, total, hipMemcpyDeviceToHost, b->stream));
+    if (qual) HIP_TRY(hipMemcpyAsync(b->h_qual, b->d_qual_out, total, hipMemcpyDeviceToHost, b->stream));
+    b->pending = true;
+    return SKH_OK;
+}
+
+int skh_count_submit(skh_ctx* ctx, skh_batch* b, uint64_t nrec, const uint8_t class_of[256], uint32_t nclass,
+                     uint64_t* counts)
+{
+    if (!ctx) return fail(SKH_EINVAL, "ctx is NULL");
+    uint64_t total = 0;
+    int rc = batch_total(b, nrec, &total);
+    if (rc) return rc;
+    if (b->ctx != ctx) return fail(SKH_EINVAL, "batch belongs to another context");
+    if (nclass < 1 || nclass > SKH_MAX_CLASSES) return fail(SKH_EINVAL, "nclass must be 1..SKH_MAX_CLASSES");
+    if (nrec == 0) return SKH_OK;
+    if (!counts) return fail(SKH_EINVAL, "counts pointer is NULL");
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (!b->d_counts) {
+        const size_t bytes = b->max_records * SKH_MAX_CLASSES * sizeof(uint64_t);
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&b->d_counts), bytes));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&b->h_counts), bytes, hipHostMallocDefault));
+    }
+    rc = upload(b, nrec, total, false);
+    if (rc) return rc;
+    rc = skh_count_dev(ctx, b->d_seq, b->d_offs, nrec, total, class_of, nclass, b->d_counts, b->stream);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(b->h_counts, b->d_counts, nrec * nclass * sizeof(uint64_t), hipMemcpyDeviceToHost,
+                           b->stream));
+    b->user_counts = counts;
+    b->n_counts = nrec * nclass;
+    b->pending = true;
+    return SKH_OK;
+}
+
+int skh_batch_wait(skh_batch* b)
+{
+    if (!b) return fail(SKH_EINVAL, "batch is NULL");
+    if (!b->pending) return SKH_OK;
+    b->pending = false;
+    uint64_t* dst = b->user_counts;
+    const uint64_t n = b->n_counts;
+    b->user_counts = nullptr;
+    b->n_counts = 0;
+    HIP_TRY(hipSetDevice(b->ctx->device));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    if (dst && n) memcpy(dst, b->h_counts, n * sizeof(uint64_t));
+    return SKH_OK;
+}
+
+int skh_revcomp(skh_ctx* ctx, skh_batch* b, uint64_t nrec, const uint8_t* lut, int do_reverse, int reverse_qual)
+{
+    int rc = skh_revcomp_submit(ctx, b, nrec, lut, do_reverse, reverse_qual);
+    return rc ? rc : skh_batch_wait(b);
+}
+
+int skh_count(skh_ctx* ctx, skh_batch* b, uint64_t nrec, const uint8_t class_of[256], uint32_t nclass,
+              uint64_t* counts)
+{
+    int rc = skh_count_submit(ctx, b, nrec, class_of, nclass, counts);
+    return rc ? rc : skh_batch_wait(b);
+}
+
+void skh_stats_init(skh_stats_partial* p)
+{
+    if (!p) return;
+    p->num = p->len_sum = p->gap_sum = p->len_max = 0;
+    p->len_min = INT64_MAX;
+}
+
+void skh_stats_merge(skh_stats_partial* into, const skh_stats_partial* from)
+{
+    if (!into || !from) return;
+    into->num += from->num;
+    into->len_sum += from->len_sum;
+    into->gap_sum += from->gap_sum;
+    if (from->len_min < into->len_min) into->len_min = from->len_min;
+    if (from->len_max > into->len_max) into->len_max = from->len_max;
+}
+
+int skh_stats_reduce(skh_ctx* ctx, skh_batch* b, uint64_t nrec, const uint8_t is_gap[256],
+                     skh_stats_partial* inout)
+{
+    if (!ctx || !inout) return fail(SKH_EINVAL, "NULL argument");
+    uint64_t total = 0;
+    int rc = batch_total(b, nrec, &total);
+    if (rc) return rc;
+    if (b->ctx != ctx) return fail(SKH_EINVAL, "batch belongs to another context");
+    if (nrec == 0) return SKH_OK;
+    rc = upload(b, nrec, total, false);
+    if (rc) return rc;
+    rc = skh_stats_dev(ctx, b->d_seq, b->d_offs, nrec, total, is_gap,
+                       reinterpret_cast<skh_stats_partial*>(b->d_stats), b->stream);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(b->h_stats, b->d_stats, sizeof(skh::StatsPartial), hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    skh_stats_merge(inout, reinterpret_cast<const skh_stats_partial*>(b->h_stats));
+    return SKH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,34 @@
+// kernels.h -- launch interface between the C ABI (capi.hip) and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SKH_BLOCK 256          // threads per workgroup (4 wavefronts)
+#define SKH_LONG_T 32768ull    // records longer than this are served tile-wise
+#define SKH_TILE 32768ull      // bytes of plane per tile; must be >= SKH_LONG_T
+
+namespace skh {
+
+struct Table256 { uint8_t v[256]; };   // passed by value in the kernel argument block
+
+struct StatsPartial { int64_t num, len_sum, gap_sum, len_min, len_max; };
+
+struct LaunchCfg {
+    int logG;            // log2 of lanes per record in the short kernels (0..6)
+    uint32_t max_grid;   // cap on workgroups of a grid-stride launch
+};
+
+// lut == nullptr: reverse only.  qin/qout == nullptr: no quality plane.
+hipError_t launch_reverse(const LaunchCfg& cfg, const uint8_t* in, uint8_t* out, const uint8_t* qin,
+                          uint8_t* qout, const uint64_t* offs, uint64_t nrec, uint64_t total,
+                          const Table256* lut, uint32_t* n_long, hipStream_t st);
+hipError_t launch_map_plane(const LaunchCfg& cfg, const uint8_t* in, uint8_t* out, uint64_t total,
+                            const Table256& lut, hipStream_t st);
+// neutral: a byte value of no class, or 256 if every byte value has a class.
+hipError_t launch_count(const LaunchCfg& cfg, const uint8_t* seq, const uint64_t* offs, uint64_t nrec,
+                        uint64_t total, const Table256& cls, uint32_t nclass, uint32_t neutral,
+                        uint64_t* counts, uint32_t* n_long, hipStream_t st);
+hipError_t launch_stats(const LaunchCfg& cfg, const uint8_t* seq, const uint64_t* offs, uint64_t nrec,
+                        uint64_t total, const Table256& is_gap, StatsPartial* out, hipStream_t st);
+
+}  // namespace skh

@@ -1,0 +1,73 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol the header declares,
+and its host-only entry points (tables, merge rule, argument errors) behave."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from seqkit_amd import build
+    build.build_lib()
+    from seqkit_amd import load
+    return load()
+
+
+def test_header_symbols_are_all_exported_and_bound(lib):
+    from seqkit_amd.capi import SYMBOLS
+    with open(os.path.join(ROOT, "include", "seqkit_hip.h")) as fh:
+        text = re.sub(r"/\*.*?\*/", "", fh.read(), flags=re.S)
+    declared = set(re.findall(r"\b(skh_[a-z0-9_]+)\s*\(", text))
+    assert declared, "no declarations found"
+    assert declared == set(SYMBOLS), (declared ^ set(SYMBOLS))
+    for name in declared:
+        assert hasattr(lib.dll, name), name
+
+
+def test_version_and_padding(lib):
+    assert b"gfx950" in lib.skh_version()
+    assert [lib.skh_padded_size(n) for n in (0, 1, 16, 17)] == [0, 16, 16, 32]
+
+
+def test_pair_tables_match_oracle(lib, oracle_lib):
+    from helpers import Oracle
+    ora = Oracle(oracle_lib)
+    for a in range(6):
+        assert bytes(lib.pair_table(a)) == ora.pair_table(a).tobytes()
+    t = (C.c_uint8 * 256)()
+    assert lib.skh_pair_table(9, t) < 0 and b"alphabet" in lib.skh_last_error()
+
+
+def test_class_table(lib):
+    t = bytes(lib.class_table(["G", "c", "AT", "-"]))
+    assert t[ord("G")] == 0 and t[ord("g")] == 0 and t[ord("C")] == 1 and t[ord("c")] == 1
+    assert t[ord("a")] == 2 and t[ord("T")] == 2 and t[ord("-")] == 3 and t[ord("N")] == 0xFF
+    arr = (C.c_char_p * 2)(b"AC", b"c")
+    out = (C.c_uint8 * 256)()
+    assert lib.skh_class_table(arr, 2, out) < 0
+
+
+def test_stats_merge_rule(lib):
+    from seqkit_amd import StatsPartial
+    a, b = StatsPartial(), StatsPartial()
+    lib.skh_stats_init(C.byref(a)); lib.skh_stats_init(C.byref(b))
+    assert a.as_tuple() == (0, 0, 0, 2**63 - 1, 0)
+    b.num, b.len_sum, b.gap_sum, b.len_min, b.len_max = 3, 30, 2, 5, 15
+    lib.skh_stats_merge(C.byref(a), C.byref(b))
+    b.num, b.len_sum, b.gap_sum, b.len_min, b.len_max = 1, 7, 0, 7, 7
+    lib.skh_stats_merge(C.byref(a), C.byref(b))
+    assert a.as_tuple() == (4, 37, 2, 5, 15)
+
+
+def test_init_without_gpu_fails_loudly(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    ctx = C.c_void_p()
+    assert lib.skh_init(0, C.byref(ctx)) == -2
+    assert b"device" in lib.skh_last_error().lower()
