@@ -126,8 +126,12 @@ def main():
     counts = torch.empty(nrec * 4, dtype=torch.int64, device=dev)
     lut = lib.pair_table(1)                          # DNAredundant (reader's guess for ACGTN reads)
     cls = lib.class_table(["G", "C", "A", "T"])      # fx2tab -g -B AGCT needs G, C and A+T
-    stream = torch.cuda.current_stream()
+    # a stream of our own with a non-null handle: the library launches on exactly this
+    # stream and the HIP events below are recorded on it
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()
     sp = C.c_void_p(stream.cuda_stream)
+    assert stream.cuda_stream != 0
     p = lambda t: C.c_void_p(t.data_ptr())
 
     def revcomp():

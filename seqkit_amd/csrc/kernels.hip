@@ -69,41 +69,64 @@ __device__ __forceinline__ uint64_t find_record(const uint64_t* __restrict__ off
 }
 
 // ------------------------------------------------------------------ reverse (+complement)
+//
+// out[p] = lut[in[s + e - 1 - p]] for every byte p of a record [s, e).
+//
+// Ownership rule: every aligned 16-byte chunk of the output plane is written once,
+// with one 16-byte store, by the lane that serves the record holding the chunk's
+// LAST byte.  A record therefore writes the chunks that end inside it; its first
+// chunk, when the record starts in the middle of it, also carries the tail bytes
+// of the previous record(s), which the same lane fetches from their mirrored
+// positions.  Nothing is ever written bytewise except the one chunk that straddles
+// the end of the plane.
+//
+// The 16 source bytes of an output chunk at plane offset o are the window
+// [q, q+16), q = s + e - 16 - o, read with ONE unaligned 16-byte load (gfx950
+// global loads take any byte address) and byte-reversed with four v_perm_b32.
 
-// Produces the 16 output bytes of the aligned output chunk at plane offset `o` of
-// the record [s, e): out[p] = in[s + e - 1 - p].  The mirrored source window
-// [q, q+16), q = s + e - 16 - o, is misaligned by delta = (s + e) mod 16, the same
-// for every chunk of the record; it is cut out of the two aligned chunks that
-// cover it with a dword barrel shift and four v_perm_b32 (which also reverse the
-// bytes).  Source chunks that hold no byte of the record are not loaded.
-__device__ __forceinline__ uint4 gather_reversed(const uint8_t* __restrict__ in, uint64_t s,
-                                                 uint64_t e, uint64_t o)
+struct RevLds {
+    uint8_t lut[256];
+    uint4 low[17];       // low[k]: 16-byte mask with the k lowest bytes set
+};
+
+template <bool COMP>
+__device__ __forceinline__ void rev_lds_init(RevLds& L, const Table256& lut)
 {
-    const int64_t q = (int64_t)(s + e) - 16 - (int64_t)o;
-    const uint32_t delta = (uint32_t)q & 15u;
-    const int64_t q0 = q - (int64_t)delta;
-    uint4 A = make_uint4(0, 0, 0, 0), B = make_uint4(0, 0, 0, 0);
-    if (q0 + 16 > (int64_t)s && q0 < (int64_t)e) A = ld16(in + q0);
-    if (delta != 0 && q0 + 32 > (int64_t)s && q0 + 16 < (int64_t)e) B = ld16(in + q0 + 16);
-
-    const bool h = (delta & 8u) != 0, l = (delta & 4u) != 0;
-    const uint32_t T0 = h ? A.z : A.x, T1 = h ? A.w : A.y, T2 = h ? B.x : A.z,
-                   T3 = h ? B.y : A.w, T4 = h ? B.z : B.x, T5 = h ? B.w : B.y;
-    const uint32_t V0 = l ? T1 : T0, V1 = l ? T2 : T1, V2 = l ? T3 : T2,
-                   V3 = l ? T4 : T3, V4 = l ? T5 : T4;
-    const uint32_t sel = 0x00010203u + (delta & 3u) * 0x01010101u;
-    uint4 r;
-    r.x = __builtin_amdgcn_perm(V4, V3, sel);
-    r.y = __builtin_amdgcn_perm(V3, V2, sel);
-    r.z = __builtin_amdgcn_perm(V2, V1, sel);
-    r.w = __builtin_amdgcn_perm(V1, V0, sel);
-    return r;
+    const uint32_t b = threadIdx.x;
+    if (COMP) L.lut[b] = lut.v[b];
+    if (b < 17) {
+        uint32_t w[4];
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            const int k = (int)b - 4 * m;
+            w[m] = k <= 0 ? 0u : (k >= 4 ? 0xffffffffu : (1u << (8 * k)) - 1u);
+        }
+        L.low[b] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    __syncthreads();
 }
+
+__device__ __forceinline__ uint4 ldu16(const uint8_t* p)     // any byte address
+{
+    uint4 v;
+    __builtin_memcpy(&v, p, 16);
+    return v;
+}
+
+__device__ __forceinline__ uint4 reverse16(uint4 w)
+{
+    return make_uint4(__builtin_bswap32(w.w), __builtin_bswap32(w.z), __builtin_bswap32(w.y),
+                      __builtin_bswap32(w.x));
+}
+
+typedef unsigned short ushort2_t __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ uint32_t map4(uint32_t w, const uint8_t* s_lut)
 {
-    return (uint32_t)s_lut[w & 0xffu] | ((uint32_t)s_lut[(w >> 8) & 0xffu] << 8) |
-           ((uint32_t)s_lut[(w >> 16) & 0xffu] << 16) | ((uint32_t)s_lut[w >> 24] << 24);
+    // two 16-bit pairs so the bytes are packed with two v_perm and one v_lshl_or
+    const ushort2_t a = {(unsigned short)s_lut[w & 0xffu], (unsigned short)s_lut[(w >> 16) & 0xffu]};
+    const ushort2_t b = {(unsigned short)s_lut[(w >> 8) & 0xffu], (unsigned short)s_lut[w >> 24]};
+    return __builtin_bit_cast(uint32_t, a) | (__builtin_bit_cast(uint32_t, b) << 8);
 }
 
 __device__ __forceinline__ uint4 map16(uint4 v, const uint8_t* s_lut)
@@ -111,75 +134,160 @@ __device__ __forceinline__ uint4 map16(uint4 v, const uint8_t* s_lut)
     return make_uint4(map4(v.x, s_lut), map4(v.y, s_lut), map4(v.z, s_lut), map4(v.w, s_lut));
 }
 
-// Stores the bytes of chunk `o` that belong to the record [s, e).  Interior chunks
-// are one 16-byte store; the first and last chunk of a record share their 16 bytes
-// with the neighbouring records, so only the owned dwords / bytes are written.
-__device__ __forceinline__ void store_owned(uint8_t* __restrict__ out, uint64_t s, uint64_t e,
-                                            uint64_t o, uint4 v)
+__device__ __forceinline__ uint4 select16(uint4 mask, uint4 a, uint4 b)    // mask ? a : b, bitwise
+{
+    return make_uint4((a.x & mask.x) | (b.x & ~mask.x), (a.y & mask.y) | (b.y & ~mask.y),
+                      (a.z & mask.z) | (b.z & ~mask.z), (a.w & mask.w) | (b.w & ~mask.w));
+}
+
+// Stores the bytes [lo_limit, hi_limit) ∩ chunk of `v` at plane offset o.  Whole
+// chunks are one 16-byte store; the partial form is only reached at the end of a plane.
+__device__ __forceinline__ void store_clipped(uint8_t* __restrict__ out, uint64_t s, uint64_t e,
+                                              uint64_t o, uint4 v)
 {
     if (o >= s && o + 16 <= e) {
         *reinterpret_cast<uint4*>(out + o) = v;
         return;
     }
-    const int lo = s > o ? (int)(s - o) : 0;                 // first owned byte of the chunk
-    const int hi = e < o + 16 ? (int)(e - o) : 16;           // one past the last owned byte
+    const int lo = s > o ? (int)(s - o) : 0;
+    const int hi = e < o + 16 ? (int)(e - o) : 16;
     const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll 1
+    for (int k = lo; k < hi; k++) {
+        const uint32_t d = k < 8 ? (k < 4 ? w[0] : w[1]) : (k < 12 ? w[2] : w[3]);
+        out[o + k] = (uint8_t)(d >> (8 * (k & 3)));
+    }
+}
+
+// Any chunk, any mix of records (tiny records, plane ends): byte p of the chunk is
+// looked up by walking the offsets down from `rec`, a record at or after the one
+// holding the chunk's last byte.  Slow, and only used where the fast forms do not apply.
+template <bool COMP, bool FASTQ>
+__device__ __noinline__ void reverse_chunk_generic(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                   const uint8_t* __restrict__ qin, uint8_t* __restrict__ qout,
+                                                   const uint64_t* __restrict__ offs, uint64_t rec,
+                                                   uint64_t total, uint64_t o, const uint8_t* s_lut)
+{
+    uint32_t w[4] = {0, 0, 0, 0}, wq[4] = {0, 0, 0, 0};
+    uint64_t r = rec;
+    const int n = total - o < 16 ? (int)(total - o) : 16;
+#pragma unroll 1
+    for (int k = n - 1; k >= 0; k--) {
+        const uint64_t p = o + (uint64_t)k;
+        while (offs[r] > p) r--;
+        const uint64_t src = offs[r] + offs[r + 1] - 1 - p;
+        uint32_t b = in[src];
+        if (COMP) b = s_lut[b];
+        const uint32_t sh = 8 * (k & 3);
+        if (k < 4) w[0] |= b << sh; else if (k < 8) w[1] |= b << sh;
+        else if (k < 12) w[2] |= b << sh; else w[3] |= b << sh;
+        if (FASTQ) {
+            const uint32_t bq = qin[src];
+            if (k < 4) wq[0] |= bq << sh; else if (k < 8) wq[1] |= bq << sh;
+            else if (k < 12) wq[2] |= bq << sh; else wq[3] |= bq << sh;
+        }
+    }
+    store_clipped(out, 0, total, o, make_uint4(w[0], w[1], w[2], w[3]));
+    if (FASTQ) store_clipped(qout, 0, total, o, make_uint4(wq[0], wq[1], wq[2], wq[3]));
+}
+
+struct RevPlanes {
+    const uint8_t* __restrict__ in;
+    uint8_t* __restrict__ out;
+    const uint8_t* __restrict__ qin;
+    uint8_t* __restrict__ qout;
+    const uint64_t* __restrict__ offs;
+    uint64_t total;
+};
+
+// Up to U chunks of one record, chunk indices k = k_first + u * k_step (relative to the
+// record's first chunk o0 = s & ~15) below k_end.  All loads are issued before the
+// first use so a lane keeps U (2U with qualities) 16-byte loads in flight.
+template <bool COMP, bool FASTQ, int U>
+__device__ __forceinline__ void reverse_batch(const RevPlanes& P, const RevLds& L, uint64_t rec,
+                                              uint64_t sprev, uint64_t s, uint64_t e, uint32_t k_first,
+                                              uint32_t k_step, uint32_t k_end)
+{
+    const uint64_t o0 = s & ~15ull;
+    const uint32_t sp = (uint32_t)(s - o0);                 // bytes of chunk 0 before the record
+    const uint64_t q_base = s + e - 16 - o0;                // window of chunk 0
+    uint4 W[U], Q[U];
 #pragma unroll
-    for (int m = 0; m < 4; m++) {
-        if (4 * m >= lo && 4 * m + 4 <= hi) {
-            *reinterpret_cast<uint32_t*>(out + o + 4 * m) = w[m];
-        } else {
+    for (int u = 0; u < U; u++) {
+        const uint32_t k = k_first + u * k_step;
+        if (k < k_end) {
+            const uint64_t q = q_base - 16ull * k;
+            W[u] = ldu16(P.in + q);
+            if (FASTQ) Q[u] = ldu16(P.qin + q);
+        }
+    }
+    // chunk 0 of a record that starts inside it: the previous record supplies bytes [0, sp)
+    const bool head = k_first == 0 && k_end != 0 && sp != 0;
+    const uint64_t padded = (P.total + 15) & ~15ull;
+    const bool head_fast = head && sprev <= o0 && sprev + sp >= 16 && e + sp <= padded;
+    uint4 HP, HQ;
+    if (head_fast) {
+        const uint64_t qp = sprev + s - 16 - o0;            // window of chunk o0 in the previous record
+        HP = ldu16(P.in + qp);
+        if (FASTQ) HQ = ldu16(P.qin + qp);
+    }
 #pragma unroll
-            for (int t = 0; t < 4; t++) {
-                const int k = 4 * m + t;
-                if (k >= lo && k < hi) out[o + k] = (uint8_t)(w[m] >> (8 * t));
+    for (int u = 0; u < U; u++) {
+        const uint32_t k = k_first + u * k_step;
+        if (k < k_end) {
+            const uint64_t o = o0 + 16ull * k;
+            if (u == 0 && head && !head_fast) {
+                reverse_chunk_generic<COMP, FASTQ>(P.in, P.out, P.qin, P.qout, P.offs, rec, P.total, o, L.lut);
+                continue;
             }
+            uint4 r = reverse16(W[u]), rq;
+            if (FASTQ) rq = reverse16(Q[u]);
+            if (u == 0 && head_fast) {
+                const uint4 m = L.low[sp];
+                r = select16(m, reverse16(HP), r);
+                if (FASTQ) rq = select16(m, reverse16(HQ), rq);
+            }
+            if (COMP) r = map16(r, L.lut);
+            *reinterpret_cast<uint4*>(P.out + o) = r;
+            if (FASTQ) *reinterpret_cast<uint4*>(P.qout + o) = rq;
         }
     }
 }
 
+// Short records: a group of 2^logG lanes per record, lane j takes chunks j, j+G, ...
+// Nothing crosses lanes, so any G gives the same bytes.
 template <bool COMP, bool FASTQ>
-__device__ __forceinline__ void reverse_chunk(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
-                                              const uint8_t* __restrict__ qin, uint8_t* __restrict__ qout,
-                                              uint64_t s, uint64_t e, uint64_t o, const uint8_t* s_lut)
+__global__ __launch_bounds__(SKH_BLOCK) void k_reverse_short(RevPlanes P, uint64_t nrec, Table256 lut,
+                                                             int logG, uint32_t* __restrict__ n_long)
 {
-    uint4 r = gather_reversed(in, s, e, o);
-    uint4 rq;
-    if (FASTQ) rq = gather_reversed(qin, s, e, o);
-    if (COMP) r = map16(r, s_lut);
-    store_owned(out, s, e, o, r);
-    if (FASTQ) store_owned(qout, s, e, o, rq);
-}
-
-// Short records: a group of 2^logG lanes per record, lane j takes output chunks
-// j, j+G, ... of the record.  Nothing crosses lanes, so any G works.
-template <bool COMP, bool FASTQ>
-__global__ __launch_bounds__(SKH_BLOCK) void k_reverse_short(
-    const uint8_t* __restrict__ in, uint8_t* __restrict__ out, const uint8_t* __restrict__ qin,
-    uint8_t* __restrict__ qout, const uint64_t* __restrict__ offs, uint64_t nrec, Table256 lut,
-    int logG, uint32_t* __restrict__ n_long)
-{
-    __shared__ uint8_t s_lut[256];
-    if (COMP) {
-        s_lut[threadIdx.x] = lut.v[threadIdx.x];
-        __syncthreads();
-    }
+    __shared__ RevLds L;
+    rev_lds_init<COMP>(L, lut);
+    constexpr int U = 4;
     const uint32_t G = 1u << logG, j = threadIdx.x & (G - 1);
     const uint64_t per_block = SKH_BLOCK >> logG;
     const uint64_t stride = (uint64_t)gridDim.x * per_block;
     uint64_t rec = (uint64_t)xcd_remap(blockIdx.x, gridDim.x) * per_block + (threadIdx.x >> logG);
-    for (; rec < nrec; rec += stride) {
-        const uint64_t s = offs[rec], e = offs[rec + 1];
-        const uint64_t L = e - s;
-        if (L > SKH_LONG_T) {
+    if (rec >= nrec) return;
+    uint64_t sprev = rec ? P.offs[rec - 1] : 0, s = P.offs[rec], e = P.offs[rec + 1];
+    while (true) {
+        // offsets of the next record of this group are requested before this one is worked on
+        const uint64_t next = rec + stride;
+        uint64_t nsprev = 0, ns = 0, ne = 0;
+        if (next < nrec) { nsprev = P.offs[next - 1]; ns = P.offs[next]; ne = P.offs[next + 1]; }
+        const uint64_t len = e - s;
+        if (len > SKH_LONG_T) {
             if (j == 0) atomicAdd(n_long, 1u);
-            continue;
+        } else if (len != 0) {
+            const uint64_t o0 = s & ~15ull;
+            const uint32_t n_own = (uint32_t)((e - o0) >> 4);       // chunks that end inside the record
+            for (uint32_t kb = 0; kb < n_own; kb += U * G)
+                reverse_batch<COMP, FASTQ, U>(P, L, rec, sprev, s, e, kb + j, G, n_own);
+            if (e == P.total && (e & 15) != 0 && j == 0)             // the chunk straddling the plane end
+                reverse_chunk_generic<COMP, FASTQ>(P.in, P.out, P.qin, P.qout, P.offs, rec, P.total,
+                                                   o0 + 16ull * n_own, L.lut);
         }
-        if (L == 0) continue;
-        const uint64_t o0 = s & ~15ull;
-        const uint32_t K = (uint32_t)((e - o0 + 15) >> 4);
-        for (uint32_t k = j; k < K; k += G)
-            reverse_chunk<COMP, FASTQ>(in, out, qin, qout, s, e, o0 + 16ull * k, s_lut);
+        if (next >= nrec) break;
+        rec = next; sprev = nsprev; s = ns; e = ne;
     }
 }
 
@@ -187,34 +295,38 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_reverse_short(
 // Only the record holding the window's first byte and the record holding its last
 // byte can be longer than TILE, so two searches find every long record it touches.
 template <bool COMP, bool FASTQ>
-__global__ __launch_bounds__(SKH_BLOCK) void k_reverse_tiles(
-    const uint8_t* __restrict__ in, uint8_t* __restrict__ out, const uint8_t* __restrict__ qin,
-    uint8_t* __restrict__ qout, const uint64_t* __restrict__ offs, uint64_t nrec, uint64_t total,
-    Table256 lut, const uint32_t* __restrict__ n_long)
+__global__ __launch_bounds__(SKH_BLOCK) void k_reverse_tiles(RevPlanes P, uint64_t nrec, Table256 lut,
+                                                             const uint32_t* __restrict__ n_long)
 {
     if (*n_long == 0) return;
-    __shared__ uint8_t s_lut[256];
-    if (COMP) {
-        s_lut[threadIdx.x] = lut.v[threadIdx.x];
-        __syncthreads();
-    }
+    __shared__ RevLds L;
+    rev_lds_init<COMP>(L, lut);
+    constexpr int U = 4;
+    const uint64_t total = P.total;
     const uint64_t ntiles = (total + SKH_TILE - 1) / SKH_TILE;
     for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const uint64_t t0 = tile * SKH_TILE;
         const uint64_t t1 = t0 + SKH_TILE;                       // exclusive, may exceed total
         const uint64_t last = (t1 < total ? t1 : total) - 1;     // last real byte of the window
-        const uint64_t r_lo = find_record(offs, nrec, t0);
-        const uint64_t r_hi = find_record(offs, nrec, last);
+        const uint64_t r_lo = find_record(P.offs, nrec, t0);
+        const uint64_t r_hi = find_record(P.offs, nrec, last);
 #pragma unroll 1
         for (int c = 0; c < 2; c++) {
             if (c == 1 && r_hi == r_lo) break;
             const uint64_t r = c == 0 ? r_lo : r_hi;
-            const uint64_t s = offs[r], e = offs[r + 1];
+            const uint64_t s = P.offs[r], e = P.offs[r + 1];
             if (e - s <= SKH_LONG_T) continue;
-            const uint64_t a = s & ~15ull, b = (e + 15) & ~15ull;
-            const uint64_t c0 = a > t0 ? a : t0, c1 = b < t1 ? b : t1;
-            for (uint64_t o = c0 + 16ull * threadIdx.x; o < c1; o += 16ull * SKH_BLOCK)
-                reverse_chunk<COMP, FASTQ>(in, out, qin, qout, s, e, o, s_lut);
+            const uint64_t sprev = r ? P.offs[r - 1] : 0;
+            const uint64_t o0 = s & ~15ull;
+            const uint32_t n_own = (uint32_t)((e - o0) >> 4);    // < 2^28 chunks: records < 4 GiB
+            // owned chunks of the record that lie in this window: indices [k0, k1)
+            const uint32_t k0 = o0 >= t0 ? 0u : (uint32_t)((t0 - o0) >> 4);
+            const uint64_t own_end = o0 + 16ull * n_own;
+            const uint32_t k1 = own_end <= t1 ? n_own : (uint32_t)((t1 - o0) >> 4);
+            for (uint32_t kb = k0; kb < k1; kb += U * SKH_BLOCK)
+                reverse_batch<COMP, FASTQ, U>(P, L, r, sprev, s, e, kb + threadIdx.x, SKH_BLOCK, k1);
+            if (e == total && (e & 15) != 0 && own_end >= t0 && own_end < t1 && threadIdx.x == 0)
+                reverse_chunk_generic<COMP, FASTQ>(P.in, P.out, P.qin, P.qout, P.offs, r, total, own_end, L.lut);
         }
     }
 }
@@ -232,7 +344,7 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_map_plane(const uint8_t* __restri
     for (uint64_t c = (uint64_t)blockIdx.x * SKH_BLOCK + threadIdx.x; c < nchunk; c += stride) {
         const uint64_t o = c << 4;
         const uint4 v = map16(ld16(in + o), s_lut);
-        store_owned(out, 0, total, o, v);
+        store_clipped(out, 0, total, o, v);
     }
 }
 
@@ -544,12 +656,13 @@ static hipError_t launch_reverse_t(const LaunchCfg& cfg, const uint8_t* in, uint
                                    uint64_t nrec, uint64_t total, const Table256& lut,
                                    uint32_t* n_long, hipStream_t st)
 {
+    const RevPlanes P{in, out, qin, qout, offs, total};
     const uint32_t g1 = grid_for(nrec, SKH_BLOCK >> cfg.logG, cfg.max_grid);
-    hipLaunchKernelGGL((k_reverse_short<COMP, FASTQ>), dim3(g1), dim3(SKH_BLOCK), 0, st, in, out, qin,
-                       qout, offs, nrec, lut, cfg.logG, n_long);
+    hipLaunchKernelGGL((k_reverse_short<COMP, FASTQ>), dim3(g1), dim3(SKH_BLOCK), 0, st, P, nrec, lut,
+                       cfg.logG, n_long);
     const uint32_t g2 = grid_for((total + SKH_TILE - 1) / SKH_TILE, 1, cfg.max_grid);
-    hipLaunchKernelGGL((k_reverse_tiles<COMP, FASTQ>), dim3(g2), dim3(SKH_BLOCK), 0, st, in, out, qin,
-                       qout, offs, nrec, total, lut, n_long);
+    hipLaunchKernelGGL((k_reverse_tiles<COMP, FASTQ>), dim3(g2), dim3(SKH_BLOCK), 0, st, P, nrec, lut,
+                       n_long);
     return hipGetLastError();
 }
 
