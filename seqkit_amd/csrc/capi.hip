@@ -55,6 +55,8 @@ struct skh_ctx {
     std::atomic<uint32_t> flag_next{0};
     uint32_t max_grid = 2048;
     int force_logG = -1;
+    int span_u = 4;
+    int fuse_fastq = 0;
 };
 
 struct skh_batch {
@@ -80,6 +82,8 @@ skh::LaunchCfg cfg_for(const skh_ctx* ctx, uint64_t nrec, uint64_t total)
 {
     skh::LaunchCfg c;
     c.max_grid = ctx->max_grid;
+    c.span_u = ctx->span_u;
+    c.fuse_fastq = ctx->fuse_fastq;
     if (ctx->force_logG >= 0) {
         c.logG = ctx->force_logG > 6 ? 6 : ctx->force_logG;
         return c;
@@ -133,6 +137,8 @@ int skh_init(int device, skh_ctx** out)
     c->max_grid = (uint32_t)env_int("SKH_MAX_GRID", prop.multiProcessorCount * 8);
     if (c->max_grid < 1) c->max_grid = 1;
     c->force_logG = env_int("SKH_LOGG", -1);
+    c->span_u = env_int("SKH_SPAN_U", 0);
+    c->fuse_fastq = env_int("SKH_FUSE_FASTQ", 0);
     e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->d_flags), N_FLAGS * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemset(c->d_flags, 0, N_FLAGS * sizeof(uint32_t));

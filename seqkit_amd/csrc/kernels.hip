@@ -200,56 +200,123 @@ struct RevPlanes {
     uint64_t total;
 };
 
+// The window [q, q+16) of the 32 bytes lo‖hi (two adjacent aligned chunks, window offset
+// dq = q mod 16), byte-reversed: a dword barrel shift and four v_perm_b32.
+__device__ __forceinline__ uint4 window_reversed(uint4 lo, uint4 hi, uint32_t dq)
+{
+    const bool h = (dq & 8u) != 0, l = (dq & 4u) != 0;
+    const uint32_t T0 = h ? lo.z : lo.x, T1 = h ? lo.w : lo.y, T2 = h ? hi.x : lo.z,
+                   T3 = h ? hi.y : lo.w, T4 = h ? hi.z : hi.x, T5 = h ? hi.w : hi.y;
+    const uint32_t V0 = l ? T1 : T0, V1 = l ? T2 : T1, V2 = l ? T3 : T2,
+                   V3 = l ? T4 : T3, V4 = l ? T5 : T4;
+    const uint32_t sel = 0x00010203u + (dq & 3u) * 0x01010101u;
+    return make_uint4(__builtin_amdgcn_perm(V4, V3, sel), __builtin_amdgcn_perm(V3, V2, sel),
+                      __builtin_amdgcn_perm(V2, V1, sel), __builtin_amdgcn_perm(V1, V0, sel));
+}
+
+__device__ __forceinline__ uint4 shfl16(uint4 v, int src_lane)
+{
+    return make_uint4(__shfl(v.x, src_lane), __shfl(v.y, src_lane), __shfl(v.z, src_lane),
+                      __shfl(v.w, src_lane));
+}
+
 // Up to U chunks of one record, chunk indices k = k_first + u * k_step (relative to the
-// record's first chunk o0 = s & ~15) below k_end.  All loads are issued before the
-// first use so a lane keeps U (2U with qualities) 16-byte loads in flight.
-template <bool COMP, bool FASTQ, int U>
+// record's first chunk o0 = s & ~15) below k_end.
+//
+// Memory instructions are what this kernel is short of (the texture addresser spends
+// one cycle per lane on an aligned 16-byte access and two on a misaligned one), so the
+// source window of a chunk is not read directly: every lane loads the ALIGNED chunk
+// holding the start of its window, and takes the next aligned chunk -- the one its
+// window spills into -- from the lane that serves the previous chunk of the record,
+// whose own aligned chunk it is.  Only a chunk without such a neighbour (the first of a
+// record, or lane 0 of a wavefront in ROW order) loads its second chunk itself.
+// ROW = false: lanes of a group are k_step = G apart (chunk k-1 sits in lane-1, or in
+// lane+G-1 one step of u earlier); ROW = true: k_step = 256, chunk k-1 is lane-1 of the
+// same wavefront.  All loads are issued before the first use.
+template <bool COMP, bool FASTQ, int U, bool ROW>
 __device__ __forceinline__ void reverse_batch(const RevPlanes& P, const RevLds& L, uint64_t rec,
                                               uint64_t sprev, uint64_t s, uint64_t e, uint32_t k_first,
                                               uint32_t k_step, uint32_t k_end)
 {
+    const uint32_t lane = threadIdx.x & 63;
     const uint64_t o0 = s & ~15ull;
     const uint32_t sp = (uint32_t)(s - o0);                 // bytes of chunk 0 before the record
     const uint64_t q_base = s + e - 16 - o0;                // window of chunk 0
-    uint4 W[U], Q[U];
+    const uint32_t dq = (uint32_t)q_base & 15u;             // the same for every chunk of the record
+    const uint64_t a_base = q_base - dq;
+    const uint64_t padded = (P.total + 15) & ~15ull;
+    constexpr int NE = ROW ? U : 1;
+    uint4 W[U], Q[U], E[NE], EQ[NE];
+    bool own_upper[NE];
 #pragma unroll
     for (int u = 0; u < U; u++) {
         const uint32_t k = k_first + u * k_step;
+        W[u] = make_uint4(0, 0, 0, 0);
+        if (FASTQ) Q[u] = make_uint4(0, 0, 0, 0);
         if (k < k_end) {
-            const uint64_t q = q_base - 16ull * k;
-            W[u] = ldu16(P.in + q);
-            if (FASTQ) Q[u] = ldu16(P.qin + q);
+            const uint64_t a = a_base - 16ull * k;
+            W[u] = ld16(P.in + a);
+            if (FASTQ) Q[u] = ld16(P.qin + a);
+        }
+        if (u < NE) {
+            // group order: only the group's first lane in its first step lacks a neighbour
+            own_upper[u] = k < k_end && dq != 0 && (ROW ? lane == 0 : (u == 0 && k_first % k_step == 0));
+            E[u] = make_uint4(0, 0, 0, 0);
+            EQ[u] = make_uint4(0, 0, 0, 0);
+            if (own_upper[u]) {
+                const uint64_t a = a_base - 16ull * k + 16;
+                if (a + 16 <= padded) {                      // beyond the plane only bytes nobody needs
+                    E[u] = ld16(P.in + a);
+                    if (FASTQ) EQ[u] = ld16(P.qin + a);
+                }
+            }
         }
     }
     // chunk 0 of a record that starts inside it: the previous record supplies bytes [0, sp)
     const bool head = k_first == 0 && k_end != 0 && sp != 0;
-    const uint64_t padded = (P.total + 15) & ~15ull;
-    const bool head_fast = head && sprev <= o0 && sprev + sp >= 16 && e + sp <= padded;
-    uint4 HP, HQ;
+    const bool head_fast = head && sprev <= o0 && sprev + sp >= 16;
+    uint4 HP = make_uint4(0, 0, 0, 0), HQ = make_uint4(0, 0, 0, 0);
     if (head_fast) {
         const uint64_t qp = sprev + s - 16 - o0;            // window of chunk o0 in the previous record
-        HP = ldu16(P.in + qp);
+        HP = ldu16(P.in + qp);                              // one lane per record: misaligned is cheap here
         if (FASTQ) HQ = ldu16(P.qin + qp);
     }
+    // Every lane runs the arithmetic below (the cross-lane reads must not sit in a
+    // lane-divergent branch); lanes without a chunk compute on stale registers and skip the store.
 #pragma unroll
     for (int u = 0; u < U; u++) {
         const uint32_t k = k_first + u * k_step;
+        const uint64_t o = o0 + 16ull * k;
+        uint4 n = shfl16(W[u], (int)lane - 1), nq;
+        if (FASTQ) nq = shfl16(Q[u], (int)lane - 1);
+        if (!ROW && u > 0) {
+            const bool first_lane = (k_first % k_step) == 0;
+            const uint4 t = shfl16(W[u - 1], (int)(lane + k_step - 1));
+            if (first_lane) n = t;
+            if (FASTQ) {
+                const uint4 tq = shfl16(Q[u - 1], (int)(lane + k_step - 1));
+                if (first_lane) nq = tq;
+            }
+        }
+        if (u < NE) {
+            if (own_upper[u]) n = E[u];
+            if (FASTQ && own_upper[u]) nq = EQ[u];
+        }
+        uint4 r = window_reversed(W[u], n, dq), rq;
+        if (FASTQ) rq = window_reversed(Q[u], nq, dq);
+        if (u == 0 && head_fast) {
+            const uint4 m = L.low[sp];
+            r = select16(m, reverse16(HP), r);
+            if (FASTQ) rq = select16(m, reverse16(HQ), rq);
+        }
+        if (COMP) r = map16(r, L.lut);
         if (k < k_end) {
-            const uint64_t o = o0 + 16ull * k;
             if (u == 0 && head && !head_fast) {
                 reverse_chunk_generic<COMP, FASTQ>(P.in, P.out, P.qin, P.qout, P.offs, rec, P.total, o, L.lut);
-                continue;
+            } else {
+                *reinterpret_cast<uint4*>(P.out + o) = r;
+                if (FASTQ) *reinterpret_cast<uint4*>(P.qout + o) = rq;
             }
-            uint4 r = reverse16(W[u]), rq;
-            if (FASTQ) rq = reverse16(Q[u]);
-            if (u == 0 && head_fast) {
-                const uint4 m = L.low[sp];
-                r = select16(m, reverse16(HP), r);
-                if (FASTQ) rq = select16(m, reverse16(HQ), rq);
-            }
-            if (COMP) r = map16(r, L.lut);
-            *reinterpret_cast<uint4*>(P.out + o) = r;
-            if (FASTQ) *reinterpret_cast<uint4*>(P.qout + o) = rq;
         }
     }
 }
@@ -262,7 +329,7 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_reverse_short(RevPlanes P, uint64
 {
     __shared__ RevLds L;
     rev_lds_init<COMP>(L, lut);
-    constexpr int U = 4;
+    constexpr int U = 3;
     const uint32_t G = 1u << logG, j = threadIdx.x & (G - 1);
     const uint64_t per_block = SKH_BLOCK >> logG;
     const uint64_t stride = (uint64_t)gridDim.x * per_block;
@@ -281,7 +348,7 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_reverse_short(RevPlanes P, uint64
             const uint64_t o0 = s & ~15ull;
             const uint32_t n_own = (uint32_t)((e - o0) >> 4);       // chunks that end inside the record
             for (uint32_t kb = 0; kb < n_own; kb += U * G)
-                reverse_batch<COMP, FASTQ, U>(P, L, rec, sprev, s, e, kb + j, G, n_own);
+                reverse_batch<COMP, FASTQ, U, false>(P, L, rec, sprev, s, e, kb + j, G, n_own);
             if (e == P.total && (e & 15) != 0 && j == 0)             // the chunk straddling the plane end
                 reverse_chunk_generic<COMP, FASTQ>(P.in, P.out, P.qin, P.qout, P.offs, rec, P.total,
                                                    o0 + 16ull * n_own, L.lut);
@@ -324,10 +391,156 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_reverse_tiles(RevPlanes P, uint64
             const uint64_t own_end = o0 + 16ull * n_own;
             const uint32_t k1 = own_end <= t1 ? n_own : (uint32_t)((t1 - o0) >> 4);
             for (uint32_t kb = k0; kb < k1; kb += U * SKH_BLOCK)
-                reverse_batch<COMP, FASTQ, U>(P, L, r, sprev, s, e, kb + threadIdx.x, SKH_BLOCK, k1);
+                reverse_batch<COMP, FASTQ, U, true>(P, L, r, sprev, s, e, kb + threadIdx.x, SKH_BLOCK, k1);
             if (e == total && (e & 15) != 0 && own_end >= t0 && own_end < t1 && threadIdx.x == 0)
                 reverse_chunk_generic<COMP, FASTQ>(P.in, P.out, P.qin, P.qout, P.offs, r, total, own_end, L.lut);
         }
+    }
+}
+
+// ---- span form: lanes own consecutive output chunks of the plane ------------------------
+//
+// A workgroup walks a contiguous range of the plane in spans of U*256 aligned
+// 16-byte chunks; lane t owns chunks t, t+256, ... of the span, so every store
+// instruction writes 1 KiB of consecutive bytes whatever the record lengths are, and
+// work is balanced by bytes, not by records.  The offsets of the records that
+// overlap the span are staged in LDS once per span; each lane finds the owner of
+// its chunk (the record holding the chunk's last byte) by a binary search there.
+// Short and long records take the same path: a chromosome-length record is simply
+// the owner of many consecutive spans.
+constexpr int OFF_CAP = 2048;     // offsets staged per span; more records -> the span is cut short
+
+struct SpanLds {
+    RevLds tab;
+    uint64_t off[OFF_CAP];        // offs[a + t]
+    int32_t rel[OFF_CAP];         // the same relative to the span start, saturated: search keys
+    uint64_t cursor;              // owner of the span's last chunk, seeds the next span
+};
+
+template <bool COMP, bool FASTQ, int U>
+__global__ __launch_bounds__(SKH_BLOCK) void k_reverse_span(RevPlanes P, uint64_t nrec, Table256 lut)
+{
+    __shared__ SpanLds S;
+    rev_lds_init<COMP>(S.tab, lut);
+    constexpr uint32_t SPAN_CH = U * SKH_BLOCK;          // chunks per span
+    const uint32_t tid = threadIdx.x;
+    const uint64_t total = P.total, padded = (total + 15) & ~15ull;
+    const uint64_t nch = padded >> 4;
+    const uint64_t nspan = (nch + SPAN_CH - 1) / SPAN_CH;
+    const uint64_t per_block = (nspan + gridDim.x - 1) / gridDim.x;
+    const uint64_t span0 = (uint64_t)xcd_remap(blockIdx.x, gridDim.x) * per_block;
+    if (span0 >= nspan) return;
+    uint64_t c_next = span0 * SPAN_CH;
+    uint64_t c_end = (span0 + per_block) * SPAN_CH;
+    if (c_end > nch) c_end = nch;
+    // cursor: a record r_cur with offs[r_cur] <= first byte of the next span
+    uint64_t r_cur = find_record(P.offs, nrec, c_next << 4);
+
+    while (c_next < c_end) {
+        const uint64_t B0 = c_next << 4;
+        const uint32_t nc_want = c_end - c_next < SPAN_CH ? (uint32_t)(c_end - c_next) : (uint32_t)SPAN_CH;
+        const uint64_t span_last = (B0 + 16ull * nc_want < total ? B0 + 16ull * nc_want : total) - 1;
+        // ---- stage offsets a, a+1, ... until one exceeds the span's last byte
+        const uint64_t a = r_cur ? r_cur - 1 : 0;
+        // (the staged count stays a power of two so the search below can halve its step)
+        uint32_t n_staged = 0;
+        int found = 0;
+        for (uint32_t target = SKH_BLOCK; !found && target <= OFF_CAP; target <<= 1) {
+            int mine = 0;
+            for (; n_staged < target; n_staged += SKH_BLOCK) {
+                const uint32_t t = n_staged + tid;
+                const uint64_t idx = a + t;
+                const uint64_t v = idx <= nrec ? P.offs[idx] : ~0ull;
+                S.off[t] = v;
+                const int64_t d = (int64_t)(v - B0);  // v >= offs[a]: may be below B0 by any amount
+                S.rel[t] = v == ~0ull ? INT32_MAX
+                                      : (d > INT32_MAX ? INT32_MAX : (d < INT32_MIN ? INT32_MIN : (int32_t)d));
+                mine |= v > span_last;
+            }
+            found = __syncthreads_or(mine);
+        }
+        // chunks whose last byte lies below the last staged offset can be resolved
+        uint32_t nc = nc_want;
+        if (!found) {
+            const uint64_t m = S.off[n_staged - 1];
+            nc = m >= B0 + 16 ? (uint32_t)((m - B0) >> 4) : 0u;
+            if (nc > nc_want) nc = nc_want;
+        }
+        if (nc == 0) {
+            // more than OFF_CAP records end inside one chunk (runs of empty records): one lane
+            // resolves this single chunk from global memory
+            const uint64_t pl = B0 + 15 < total ? B0 + 15 : total - 1;
+            const uint64_t r = find_record(P.offs, nrec, pl);
+            if (tid == 0)
+                reverse_chunk_generic<COMP, FASTQ>(P.in, P.out, P.qin, P.qout, P.offs, r, total, B0, S.tab.lut);
+            __syncthreads();
+            r_cur = r;
+            c_next += 1;
+            continue;
+        }
+
+        // ---- per chunk: owner search, window addresses, loads (all issued before first use)
+        uint4 W[U], Q[U], HP[U], HQ[U];
+        uint32_t kind[U];         // 0 none, 1 interior, 2 head (two windows), 3 generic; bits 8.. = sp
+        uint64_t own[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t c = tid + u * SKH_BLOCK;
+            kind[u] = 0;
+            own[u] = 0;
+            if (c < nc) {
+                const uint64_t o = B0 + 16ull * c;
+                const int32_t p_rel = (o + 15 < total ? 16 * (int32_t)c + 15 : (int32_t)(total - 1 - B0));
+                uint32_t i = 0;
+                for (uint32_t step = n_staged >> 1; step != 0; step >>= 1)
+                    if (S.rel[i + step] <= p_rel) i += step;
+                const uint64_t s = S.off[i], e = S.off[i + 1];
+                const uint64_t sprev = i ? S.off[i - 1] : 0;
+                own[u] = a + i;
+                const uint64_t q = s + e - 16 - o;
+                if (o + 16 > total) {
+                    kind[u] = 3;                                  // the chunk straddling the plane end
+                } else if (o >= s) {
+                    kind[u] = 1;
+                    W[u] = ldu16(P.in + q);
+                    if (FASTQ) Q[u] = ldu16(P.qin + q);
+                } else {
+                    const uint32_t sp = (uint32_t)(s - o);        // bytes of the chunk before the owner
+                    if (sprev <= o && sprev + sp >= 16 && e + sp <= padded) {
+                        kind[u] = 2 | (sp << 8);
+                        const uint64_t qp = sprev + s - 16 - o;   // window of the previous record
+                        W[u] = ldu16(P.in + q);
+                        HP[u] = ldu16(P.in + qp);
+                        if (FASTQ) { Q[u] = ldu16(P.qin + q); HQ[u] = ldu16(P.qin + qp); }
+                    } else {
+                        kind[u] = 3;
+                    }
+                }
+                if (c == nc - 1) S.cursor = a + i;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t k = kind[u] & 0xffu;
+            const uint64_t o = B0 + 16ull * (tid + u * SKH_BLOCK);
+            if (k == 3) {
+                reverse_chunk_generic<COMP, FASTQ>(P.in, P.out, P.qin, P.qout, P.offs, own[u], total, o, S.tab.lut);
+            } else if (k != 0) {
+                uint4 r = reverse16(W[u]), rq;
+                if (FASTQ) rq = reverse16(Q[u]);
+                if (k == 2) {
+                    const uint4 m = S.tab.low[kind[u] >> 8];
+                    r = select16(m, reverse16(HP[u]), r);
+                    if (FASTQ) rq = select16(m, reverse16(HQ[u]), rq);
+                }
+                if (COMP) r = map16(r, S.tab.lut);
+                *reinterpret_cast<uint4*>(P.out + o) = r;
+                if (FASTQ) *reinterpret_cast<uint4*>(P.qout + o) = rq;
+            }
+        }
+        __syncthreads();                     // S.off / S.rel are rewritten by the next span
+        r_cur = S.cursor;
+        c_next += nc;
     }
 }
 
@@ -651,12 +864,28 @@ static inline uint32_t grid_for(uint64_t work_items, uint64_t per_block, uint32_
 }
 
 template <bool COMP, bool FASTQ>
+static hipError_t launch_reverse_span_t(const LaunchCfg& cfg, const RevPlanes& P, uint64_t nrec,
+                                        const Table256& lut, hipStream_t st)
+{
+    const uint64_t nch = (P.total + 15) >> 4;
+    if (cfg.span_u == 2) {
+        const uint32_t g = grid_for(nch, 2 * SKH_BLOCK, cfg.max_grid);
+        hipLaunchKernelGGL((k_reverse_span<COMP, FASTQ, 2>), dim3(g), dim3(SKH_BLOCK), 0, st, P, nrec, lut);
+    } else {
+        const uint32_t g = grid_for(nch, 4 * SKH_BLOCK, cfg.max_grid);
+        hipLaunchKernelGGL((k_reverse_span<COMP, FASTQ, 4>), dim3(g), dim3(SKH_BLOCK), 0, st, P, nrec, lut);
+    }
+    return hipGetLastError();
+}
+
+template <bool COMP, bool FASTQ>
 static hipError_t launch_reverse_t(const LaunchCfg& cfg, const uint8_t* in, uint8_t* out,
                                    const uint8_t* qin, uint8_t* qout, const uint64_t* offs,
                                    uint64_t nrec, uint64_t total, const Table256& lut,
                                    uint32_t* n_long, hipStream_t st)
 {
     const RevPlanes P{in, out, qin, qout, offs, total};
+    if (cfg.span_u) return launch_reverse_span_t<COMP, FASTQ>(cfg, P, nrec, lut, st);
     const uint32_t g1 = grid_for(nrec, SKH_BLOCK >> cfg.logG, cfg.max_grid);
     hipLaunchKernelGGL((k_reverse_short<COMP, FASTQ>), dim3(g1), dim3(SKH_BLOCK), 0, st, P, nrec, lut,
                        cfg.logG, n_long);
@@ -671,7 +900,16 @@ hipError_t launch_reverse(const LaunchCfg& cfg, const uint8_t* in, uint8_t* out,
                           const Table256* lut, uint32_t* n_long, hipStream_t st)
 {
     static const Table256 ident = [] { Table256 t; for (int i = 0; i < 256; i++) t.v[i] = (uint8_t)i; return t; }();
-    const bool fastq = qin != nullptr;
+    bool fastq = qin != nullptr;
+    if (fastq && !cfg.fuse_fastq) {
+        // the two planes as two launches: half the registers per lane, twice the resident
+        // wavefronts; the offsets are read twice, which is cheaper than the lost occupancy
+        hipError_t e = launch_reverse(cfg, qin, qout, nullptr, nullptr, offs, nrec, total, nullptr, n_long, st);
+        if (e != hipSuccess) return e;
+        fastq = false;
+        qin = nullptr;
+        qout = nullptr;
+    }
     if (lut) {
         return fastq ? launch_reverse_t<true, true>(cfg, in, out, qin, qout, offs, nrec, total, *lut, n_long, st)
                      : launch_reverse_t<true, false>(cfg, in, out, qin, qout, offs, nrec, total, *lut, n_long, st);

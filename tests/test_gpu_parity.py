@@ -22,9 +22,16 @@ def lib():
     return load()
 
 
-@pytest.fixture(scope="module")
-def ctx(lib):
+@pytest.fixture(scope="module", params=["span", "groups"])
+def ctx(lib, request):
+    # both reverse implementations must give the same bytes (SKH_SPAN_U is read by skh_init)
+    old = os.environ.get("SKH_SPAN_U")
+    os.environ["SKH_SPAN_U"] = "4" if request.param == "span" else "0"
     c = lib.init(0)
+    if old is None:
+        del os.environ["SKH_SPAN_U"]
+    else:
+        os.environ["SKH_SPAN_U"] = old
     yield c
     lib.skh_destroy(c)
 
@@ -101,6 +108,7 @@ def test_transform_matches_oracle(lib, ctx, ora, case, mode):
 def test_every_group_width(lib, ora, logg, monkeypatch):
     # the lanes-per-record choice is a speed knob: every width must give the same bytes
     monkeypatch.setenv("SKH_LOGG", str(logg))
+    monkeypatch.setenv("SKH_SPAN_U", "0")
     c = lib.init(0)
     try:
         lengths = np.concatenate([CASES["ragged0_300"][:700], [40000, 0, 33000, 17], CASES["tiny0_20"][:300],

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Times individual entry points on a resident 10M x 150 batch (GPU only): isolates where a
+kernel's time goes (window loads vs table lookups vs stores)."""
+import ctypes as C, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import seqkit_amd
+from bench import synth_fastq
+
+nrec = int(os.environ.get("NREC", 10_000_000)); L = int(os.environ.get("READLEN", 150))
+dev = torch.device("cuda", 0)
+lib = seqkit_amd.load(); ctx = lib.init(0)
+seq, qual, offs = synth_fastq(nrec, L, 0xC2, dev)
+total = nrec * L
+so, qo = torch.empty_like(seq), torch.empty_like(qual)
+counts = torch.empty(nrec * 8, dtype=torch.int64, device=dev)
+stats = torch.zeros(5, dtype=torch.int64, device=dev)
+lut = lib.pair_table(1); cls4 = lib.class_table(["G", "C", "A", "T"]); cls6 = lib.class_table(["G", "C", "A", "T", "N", "-"])
+gap = (C.c_uint8 * 256)(); gap[ord("-")] = 1
+torch.cuda.synchronize()   # data was generated on the default stream
+st = torch.cuda.Stream(device=dev); sp = C.c_void_p(st.cuda_stream)
+p = lambda t: C.c_void_p(t.data_ptr())
+GB = 1e9
+cases = {
+    "revcomp_fastq (4B/base)": (lambda: lib.skh_revcomp_fastq_dev(ctx, p(seq), p(so), p(qual), p(qo), p(offs), nrec, total, lut, 1, sp), 4 * total),
+    "revcomp seq only (2B/base)": (lambda: lib.skh_revcomp_dev(ctx, p(seq), p(so), p(offs), nrec, total, lut, 1, sp), 2 * total),
+    "reverse only, no table (2B/base)": (lambda: lib.skh_revcomp_dev(ctx, p(seq), p(so), p(offs), nrec, total, None, 1, sp), 2 * total),
+    "reverse fastq, no table (4B/base)": (lambda: lib.skh_revcomp_fastq_dev(ctx, p(seq), p(so), p(qual), p(qo), p(offs), nrec, total, None, 1, sp), 4 * total),
+    "complement only (aligned, 2B/base)": (lambda: lib.skh_revcomp_dev(ctx, p(seq), p(so), p(offs), nrec, total, lut, 0, sp), 2 * total),
+    "count 4 classes (1B/base+40B/rec)": (lambda: lib.skh_count_dev(ctx, p(seq), p(offs), nrec, total, cls4, 4, p(counts), sp), total + 40 * nrec),
+    "count 6 classes (1B/base+56B/rec)": (lambda: lib.skh_count_dev(ctx, p(seq), p(offs), nrec, total, cls6, 6, p(counts), sp), total + 56 * nrec),
+    "stats (1B/base+8B/rec)": (lambda: lib.skh_stats_dev(ctx, p(seq), p(offs), nrec, total, gap, p(stats), sp), total + 8 * nrec),
+}
+with torch.cuda.stream(st):
+    cases["torch copy_ (2B/base)"] = (lambda: (so.copy_(seq), 0)[1], 2 * total)
+    for name, (fn, nbytes) in cases.items():
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        for _ in range(10):
+            fn()
+        e1.record(st)
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        print("%-40s %8.3f ms  %7.1f GB/s  %5.1f%% of 8 TB/s  %8.1f Gbases/s" % (name, ms, nbytes / ms / 1e6, nbytes / ms / 1e6 / 80, total / ms / 1e6))
+lib.skh_destroy(ctx)
