@@ -30,6 +30,16 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak
 
 
+def measured_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/), valid
+    for the default workload only; None otherwise."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as fh:
+            return json.load(fh)["kernels"][kernel]["hbm_bytes"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -134,9 +144,14 @@ def main():
     assert stream.cuda_stream != 0
     p = lambda t: C.c_void_p(t.data_ptr())
 
-    def revcomp():
-        lib.check(lib.skh_revcomp_fastq_dev(ctx, p(seq), p(seq_out), p(qual), p(qual_out), p(offs), nrec, total,
-                                            lut, 1, sp))
+    # seq -r -p on FASTQ = bases reversed + complemented, qualities reversed.  The library runs
+    # the two planes as two launches of the same kernel; they are issued separately here so
+    # that each can be timed on its own (skh_revcomp_fastq_dev does exactly these two calls).
+    def revcomp_bases():
+        lib.check(lib.skh_revcomp_dev(ctx, p(seq), p(seq_out), p(offs), nrec, total, lut, 1, sp))
+
+    def reverse_quals():
+        lib.check(lib.skh_revcomp_dev(ctx, p(qual), p(qual_out), p(offs), nrec, total, None, 1, sp))
 
     def count():
         lib.check(lib.skh_count_dev(ctx, p(seq), p(offs), nrec, total, cls, 4, p(counts), sp))
@@ -147,16 +162,18 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        revcomp(); count()
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+        revcomp_bases(); reverse_quals(); count()
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
     barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
         ev[k][0].record(stream)
-        revcomp()
+        revcomp_bases()
         ev[k][1].record(stream)
-        count()
+        reverse_quals()
         ev[k][2].record(stream)
+        count()
+        ev[k][3].record(stream)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -164,7 +181,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     rev_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / args.steps
-    cnt_ms = sum(e[1].elapsed_time(e[2]) for e in ev) / args.steps
+    qual_ms = sum(e[1].elapsed_time(e[2]) for e in ev) / args.steps
+    cnt_ms = sum(e[2].elapsed_time(e[3]) for e in ev) / args.steps
 
     # `stats` totals: per-GPU partial on the device, then the path's one collective
     stats_d = torch.zeros(5, dtype=torch.int64, device=dev)
@@ -206,9 +224,10 @@ def main():
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = world * total * args.steps / elapsed / 1e9
-        rev_bytes = 4.0 * total + 8.0 * (nrec + 1)          # seq r+w, qual r+w, offsets
+        rev_bytes = 2.0 * total + 8.0 * (nrec + 1)          # one plane read + written, offsets read
         cnt_bytes = 1.0 * total + 8.0 * (nrec + 1) + 32.0 * nrec
         achieved = rev_bytes / (rev_ms * 1e-3) / 1e9
+        gbs = lambda nbytes, ms: round(nbytes / (ms * 1e-3) / 1e9, 1)
         out = {
             "metric": "Gbases/sec revcomp+base-count (kernel & end-to-end), 1-8 MI355X; % HBM peak",
             "value": round(value, 3), "unit": "Gbases/s", "n_gpus": world, "steps": args.steps,
@@ -218,13 +237,22 @@ def main():
                                    "(reverse-complement + quality reversal) then fx2tab -g -B AGCT counts, "
                                    "resident in HBM" % (nrec, L),
                        "records_per_gpu": nrec, "read_len": L, "parallelism": "records sharded, %d rank(s)" % world},
-            "roofline": {"bound": "hbm", "kernel": "k_reverse_short<COMP,FASTQ>", "achieved": round(achieved, 1),
+            "roofline": {"bound": "hbm", "kernel": "skh::k_reverse_short<true, false> (bases: reverse + complement)",
+                         "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": None, "algorithmic_bytes_per_launch": rev_bytes,
+                         "traffic": measured_traffic("skh::k_reverse_short<true, false>")
+                         if (nrec, L) == (10_000_000, 150) else None,
+                         "algorithmic_bytes_per_launch": rev_bytes,
                          "avg_launch_ms": round(rev_ms, 4)},
             "kernels": {
-                "revcomp_fastq": {"ms": round(rev_ms, 4), "gbases_per_s": round(total / rev_ms / 1e6, 1),
-                                  "algorithmic_GBps": round(achieved, 1)},
+                "revcomp_bases": {"ms": round(rev_ms, 4), "gbases_per_s": round(total / rev_ms / 1e6, 1),
+                                  "algorithmic_GBps": gbs(rev_bytes, rev_ms),
+                                  "frac": round(gbs(rev_bytes, rev_ms) / HBM_PEAK_GBS, 4)},
+                "reverse_quals": {"ms": round(qual_ms, 4), "algorithmic_GBps": gbs(rev_bytes, qual_ms),
+                                  "frac": round(gbs(rev_bytes, qual_ms) / HBM_PEAK_GBS, 4)},
+                "seq_r_p_fastq": {"ms": round(rev_ms + qual_ms, 4),
+                                  "gbases_per_s": round(total / (rev_ms + qual_ms) / 1e6, 1),
+                                  "algorithmic_GBps": gbs(2 * rev_bytes, rev_ms + qual_ms)},
                 "count4": {"ms": round(cnt_ms, 4), "gbases_per_s": round(total / cnt_ms / 1e6, 1),
                            "algorithmic_GBps": round(cnt_bytes / (cnt_ms * 1e-3) / 1e9, 1),
                            "frac": round(cnt_bytes / (cnt_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
