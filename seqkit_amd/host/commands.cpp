@@ -1,0 +1,381 @@
+// commands.cpp -- `seq`, `fx2tab`, `stats` on top of the C ABI.
+//
+// Each command mirrors the record loop of its Go counterpart (seqkit/cmd/seq.go:114-280,
+// fx2tab.go:95-150, stat.go:86-161) but works a batch at a time: while the GPU transforms or
+// counts batch i, the host formats batch i-1 and parses batch i+1 (two pinned batches,
+// skh_*_submit / skh_batch_wait).
+#include <algorithm>
+#include <climits>
+#include <cstring>
+
+#include "host.h"
+
+namespace host {
+
+namespace {
+
+struct Ctx {
+    skh_ctx* c = nullptr;
+    ~Ctx() { if (c) skh_destroy(c); }
+};
+
+struct TwoBatches {
+    Batch bt[2];
+    ~TwoBatches() { for (auto& b : bt) if (b.b) skh_batch_free(b.b); }
+};
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------ seq
+int cmd_seq(const GlobalOpts& g, const SeqOpts& o, const std::vector<std::string>& files)
+{
+    Ctx ctx;
+    if (skh_init(g.device, &ctx.c) != SKH_OK) return fatal(skh_last_error());
+    Sink out(g.out_file);
+    if (!out.ok()) return fatal("open " + g.out_file + ": cannot create");
+    bool is_fastq = false, check_type = true;        // seq.go:105-106: decided once, by the first record
+    TwoBatches tb;
+
+    for (const std::string& file : files) {
+        FastxReader rd(ctx.c, file, g.alphabet, g.guess_len);
+        if (!rd.ok()) return fatal(rd.error());
+        uint8_t lut[256];
+        bool lut_ready = false, warned = false;
+
+        // prints a finished batch (seq.go:163-276)
+        auto emit = [&](Batch& bt) -> int {
+            const int width = rd.is_fastq() ? 0 : g.line_width;        // seq.go:136-138
+            const uint64_t* off = bt.offs();
+            for (uint64_t r = 0; r < bt.nrec; r++) {
+                const uint64_t len = off[r + 1] - off[r];
+                if (o.min_len >= 0 && len < (uint64_t)o.min_len) continue;
+                if (o.max_len >= 0 && len > (uint64_t)o.max_len) continue;
+                if (check_type) { is_fastq = rd.is_fastq() && len > 0; check_type = false; }
+                bool pq = is_fastq, pn = true, ps = true;
+                if (o.only_name && o.only_seq) { pn = ps = true; }
+                else if (o.only_name) { ps = false; pq = false; }
+                else if (o.only_seq) { pn = false; pq = false; }
+                else if (o.only_qual) {
+                    if (!is_fastq) return fatal("FASTA format has no quality. So do not just use flag -q (--qual)");
+                    pn = false; ps = false; pq = true;
+                }
+                if (pn) {
+                    const char* name = bt.names.data() + bt.name_off[r];
+                    const size_t nl = o.only_id ? bt.id_len[r] : (size_t)(bt.name_off[r + 1] - bt.name_off[r]);
+                    if (ps) out.put(is_fastq ? '@' : '>');
+                    out.write(name, nl);
+                    out.put('\n');
+                }
+                if (ps) { write_wrapped(out, bt.seq() + off[r], len, width); out.put('\n'); }
+                if (pq) {
+                    if (!o.only_qual) out.puts("+\n");
+                    if (bt.qual()) write_wrapped(out, bt.qual() + off[r], len, width);
+                    out.put('\n');
+                }
+            }
+            return 0;
+        };
+
+        int cur = 0;
+        bool have_prev = false;
+        for (;;) {
+            Batch& bt = tb.bt[cur];
+            const bool got = rd.next_batch(bt, g.batch_bytes, g.batch_records);
+            if (!rd.error().empty()) return fatal("error when parsing " + file + ": " + rd.error());
+            if (got) {
+                if (o.complement && !lut_ready) {
+                    const int ab = rd.alphabet();
+                    if (!g.quiet && (ab == Protein || ab == Unlimit) && !warned) {
+                        fprintf(stderr, "[WARN] Complement does no take effect on protein/unlimit sequence\n");
+                        warned = true;
+                    }
+                    skh_pair_table(ab, lut);
+                    lut_ready = true;
+                }
+                if (o.reverse || o.complement) {
+                    // seq.go:187-195: ReverseInplace (bases and qualities), then ComplementInplace
+                    if (skh_revcomp_submit(ctx.c, bt.b, bt.nrec, o.complement ? lut : nullptr, o.reverse, 1) != SKH_OK)
+                        return fatal(skh_last_error());
+                }
+            }
+            if (have_prev) {
+                Batch& pv = tb.bt[cur ^ 1];
+                if (skh_batch_wait(pv.b) != SKH_OK) return fatal(skh_last_error());
+                if (int rc = emit(pv)) return rc;
+            }
+            if (!got) break;
+            have_prev = true;
+            cur ^= 1;
+        }
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------ fx2tab
+int cmd_fx2tab(const GlobalOpts& g, const Fx2tabOpts& o, const std::vector<std::string>& files)
+{
+    Ctx ctx;
+    if (skh_init(g.device, &ctx.c) != SKH_OK) return fatal(skh_last_error());
+    Sink out(g.out_file);
+    if (!out.ok()) return fatal("open " + g.out_file + ": cannot create");
+
+    // BaseContent(list) = sum over the bytes of `list` (duplicates count again) of the
+    // occurrences of the byte in either case (fx2tab.go:128,129,141).  One GPU class per
+    // distinct case-folded byte that any requested list mentions; the lists are then sums of
+    // class counts.  More than SKH_MAX_CLASSES distinct bytes take further counting passes.
+    std::vector<uint8_t> letters;                    // distinct folded bytes, in first-use order
+    auto fold = [](uint8_t b) { return (uint8_t)((b >= 'a' && b <= 'z') ? b - 32 : b); };
+    auto want = [&](const std::string& list) {
+        for (unsigned char ch : list) {
+            const uint8_t f = fold(ch);
+            if (std::find(letters.begin(), letters.end(), f) == letters.end()) letters.push_back(f);
+        }
+    };
+    if (o.gc || o.gc_skew) { want("G"); want("C"); }
+    for (const auto& bc : o.base) want(bc);
+    const size_t npass = (letters.size() + SKH_MAX_CLASSES - 1) / SKH_MAX_CLASSES;
+    std::vector<std::vector<uint8_t>> pass_table(npass, std::vector<uint8_t>(256, SKH_NO_CLASS));
+    std::vector<uint32_t> pass_nclass(npass, 0);
+    for (size_t i = 0; i < letters.size(); i++) {
+        const size_t ps = i / SKH_MAX_CLASSES;
+        const uint8_t cls = (uint8_t)(i % SKH_MAX_CLASSES), up = letters[i];
+        pass_table[ps][up] = cls;
+        if (up >= 'A' && up <= 'Z') pass_table[ps][up + 32] = cls;
+        pass_nclass[ps] = cls + 1u;
+    }
+    auto letter_index = [&](uint8_t ch) {
+        return (size_t)(std::find(letters.begin(), letters.end(), fold(ch)) - letters.begin());
+    };
+
+    if (o.header_line) {                             // fx2tab.go:68-89
+        out.puts("#name\tseq\tqual");
+        if (o.length) out.puts("\tlength");
+        if (o.gc) out.puts("\tGC");
+        if (o.gc_skew) out.puts("\tGC-Skew");
+        for (const auto& bc : o.base) { out.put('\t'); out.write(bc.data(), bc.size()); }
+        if (o.alphabet_col) out.puts("\talphabet");
+        out.put('\n');
+    }
+
+    TwoBatches tb;
+    std::vector<uint64_t> cnt[2];                    // per batch: nrec x letters.size(), letter-major per record
+    std::vector<uint64_t> scratch;
+    std::string num;
+    for (const std::string& file : files) {
+        FastxReader rd(ctx.c, file, Auto, g.guess_len);
+        if (!rd.ok()) return fatal(rd.error());
+
+        auto count_batch = [&](Batch& bt, std::vector<uint64_t>& dst) -> int {
+            const size_t nl = letters.size();
+            dst.assign(bt.nrec * nl, 0);
+            for (size_t ps = 0; ps < npass; ps++) {
+                const uint32_t nc = pass_nclass[ps];
+                scratch.resize(bt.nrec * nc);
+                // all but the last pass run synchronously; the last one overlaps with the host
+                if (ps + 1 < npass) {
+                    if (skh_count(ctx.c, bt.b, bt.nrec, pass_table[ps].data(), nc, scratch.data()) != SKH_OK)
+                        return fatal(skh_last_error());
+                    for (uint64_t r = 0; r < bt.nrec; r++)
+                        for (uint32_t c = 0; c < nc; c++) dst[r * nl + ps * SKH_MAX_CLASSES + c] = scratch[r * nc + c];
+                } else {
+                    bt.counts.resize(bt.nrec * nc);
+                    if (skh_count_submit(ctx.c, bt.b, bt.nrec, pass_table[ps].data(), nc, bt.counts.data()) != SKH_OK)
+                        return fatal(skh_last_error());
+                }
+            }
+            return 0;
+        };
+        auto finish_counts = [&](Batch& bt, std::vector<uint64_t>& dst) {
+            if (!npass) return;
+            const size_t nl = letters.size(), ps = npass - 1;
+            const uint32_t nc = pass_nclass[ps];
+            for (uint64_t r = 0; r < bt.nrec; r++)
+                for (uint32_t c = 0; c < nc; c++) dst[r * nl + ps * SKH_MAX_CLASSES + c] = bt.counts[r * nc + c];
+        };
+        auto base_content = [&](const uint64_t* row, const std::string& list, uint64_t len) -> double {
+            if (len == 0) return 0.0;                // BaseContent of an empty sequence
+            uint64_t sum = 0;
+            for (unsigned char ch : list) sum += row[letter_index(ch)];
+            return (double)sum / (double)len;
+        };
+        auto emit = [&](Batch& bt, const std::vector<uint64_t>& c) {
+            const uint64_t* off = bt.offs();
+            const size_t nl = letters.size();
+            for (uint64_t r = 0; r < bt.nrec; r++) {
+                const uint64_t len = off[r + 1] - off[r];
+                const char* name = bt.names.data() + bt.name_off[r];
+                out.write(name, o.only_id ? bt.id_len[r] : (size_t)(bt.name_off[r + 1] - bt.name_off[r]));
+                out.put('\t');
+                if (!o.only_name) out.write(bt.seq() + off[r], len);
+                out.put('\t');
+                if (!o.only_name && bt.qual() && rd.is_fastq()) out.write(bt.qual() + off[r], len);
+                if (o.length) { out.put('\t'); num = std::to_string(len); out.write(num.data(), num.size()); }
+                const uint64_t* row = nl ? &c[r * nl] : nullptr;
+                double gg = 0, cc = 0;
+                if (o.gc || o.gc_skew) {             // two separate divisions, then the sum (fx2tab.go:128-133)
+                    gg = base_content(row, "G", len);
+                    cc = base_content(row, "C", len);
+                }
+                if (o.gc) { fmt_fixed((gg + cc) * 100, 2, num); out.put('\t'); out.write(num.data(), num.size()); }
+                if (o.gc_skew) { fmt_fixed((gg - cc) / (gg + cc) * 100, 2, num); out.put('\t'); out.write(num.data(), num.size()); }
+                for (const auto& bc : o.base) {
+                    fmt_fixed(base_content(row, bc, len) * 100, 2, num);
+                    out.put('\t'); out.write(num.data(), num.size());
+                }
+                if (o.alphabet_col) {                // fx2tab.go:167-180 (host side; not part of the GPU path)
+                    bool present[256] = {false};
+                    for (uint64_t i = off[r]; i < off[r + 1]; i++) present[bt.seq()[i]] = true;
+                    out.put('\t');
+                    for (int b = 0; b < 256; b++) if (present[b]) out.put((char)b);
+                }
+                out.put('\n');
+            }
+        };
+
+        int cur = 0;
+        bool have_prev = false;
+        for (;;) {
+            Batch& bt = tb.bt[cur];
+            const bool got = rd.next_batch(bt, g.batch_bytes, g.batch_records);
+            if (!rd.error().empty()) return fatal("error when parsing " + file + ": " + rd.error());
+            if (got && npass) if (int rc = count_batch(bt, cnt[cur])) return rc;
+            if (have_prev) {
+                Batch& pv = tb.bt[cur ^ 1];
+                if (skh_batch_wait(pv.b) != SKH_OK) return fatal(skh_last_error());
+                finish_counts(pv, cnt[cur ^ 1]);
+                emit(pv, cnt[cur ^ 1]);
+            }
+            if (!got) break;
+            have_prev = true;
+            cur ^= 1;
+        }
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------ stats
+namespace {
+
+struct StatInfo {
+    std::string file, format, type;
+    int64_t num = 0, len_sum = 0, gap_sum = 0, len_min = 0, len_max = 0, n50 = 0, l50 = 0, q1 = 0, q2 = 0, q3 = 0;
+    double len_avg = 0;
+};
+
+int64_t median(const int64_t* sorted, size_t l)      // stat.go:297-306
+{
+    if (l == 0) return 0;
+    if (l % 2 == 0) return (sorted[l / 2 - 1] + sorted[l / 2]) / 2;
+    return sorted[l / 2];
+}
+
+}  // namespace
+
+int cmd_stats(const GlobalOpts& g, const StatsOpts& o, const std::vector<std::string>& files)
+{
+    if (o.gap_letters.empty()) return fatal("value of flag -G (--gap-letters) should not be empty");
+    uint8_t is_gap[256] = {0};
+    for (unsigned char ch : o.gap_letters) {
+        if (ch > 127) return fatal("value of -G (--gap-letters) contains non-ASCII characters");
+        is_gap[ch] = 1;
+    }
+    Ctx ctx;
+    if (skh_init(g.device, &ctx.c) != SKH_OK) return fatal(skh_last_error());
+    Sink out(g.out_file);
+    if (!out.ok()) return fatal("open " + g.out_file + ": cannot create");
+
+    std::vector<StatInfo> infos;
+    Batch bt;
+    struct Free { Batch& b; ~Free() { if (b.b) skh_batch_free(b.b); } } guard{bt};
+    for (const std::string& file : files) {
+        FastxReader rd(ctx.c, file, Auto, g.guess_len);
+        if (!rd.ok()) return fatal(rd.error());
+        skh_stats_partial tot;
+        skh_stats_init(&tot);
+        std::vector<int64_t> lens;
+        bool fastq_first = false, first = true;
+        while (rd.next_batch(bt, g.batch_bytes, g.batch_records)) {
+            if (first) { fastq_first = rd.is_fastq() && bt.offs()[1] > 0; first = false; }   // stat.go:107-113
+            // num, len_sum, gap_sum, len_min, len_max of the batch on the GPU (stat.go:106-125)
+            if (skh_stats_reduce(ctx.c, bt.b, bt.nrec, is_gap, &tot) != SKH_OK) return fatal(skh_last_error());
+            if (o.all) {
+                const uint64_t* off = bt.offs();
+                for (uint64_t r = 0; r < bt.nrec; r++) lens.push_back((int64_t)(off[r + 1] - off[r]));
+            }
+        }
+        if (!rd.error().empty()) return fatal("error when parsing " + file + ": " + rd.error());
+        StatInfo s;
+        s.file = file;
+        s.format = first ? "" : (fastq_first ? "FASTQ" : "FASTA");
+        const int ab = rd.alphabet();
+        s.type = ab == DNAredundant ? "DNA" : (ab == RNAredundant ? "RNA" : alphabet_name(ab));
+        s.len_max = tot.len_max;
+        if (tot.num != 0) {
+            s.num = tot.num; s.len_sum = tot.len_sum; s.gap_sum = tot.gap_sum; s.len_min = tot.len_min;
+            s.len_avg = round_to((double)tot.len_sum / (double)tot.num, 1);        // stat.go:158
+            if (o.all) {
+                std::sort(lens.begin(), lens.end());
+                int64_t sum = 0;                                                     // stat.go:138-145
+                for (size_t k = lens.size(); k-- > 0;) {
+                    sum += lens[k];
+                    if ((sum << 1) >= s.len_sum) { s.n50 = lens[k]; s.l50 = (int64_t)(lens.size() - k); break; }
+                }
+                const size_t l = lens.size();                                        // stat.go:308-326
+                const size_t c1 = l % 2 == 0 ? l / 2 : (l - 1) / 2, c2 = l % 2 == 0 ? l / 2 : c1 + 1;
+                s.q1 = median(lens.data(), c1);
+                s.q2 = median(lens.data(), l);
+                s.q3 = median(lens.data() + c2, l - c2);
+            }
+        }
+        infos.push_back(s);
+    }
+
+    char line[8192];
+    if (o.tabular) {                                 // stat.go:164-208
+        out.puts("file\tformat\ttype\tnum_seqs\tsum_len\tmin_len\tavg_len\tmax_len");
+        if (o.all) out.puts("\tQ1\tQ2\tQ3\tsum_gap\tN50");
+        out.put('\n');
+        for (const StatInfo& s : infos) {
+            snprintf(line, sizeof line, "%s\t%s\t%s\t%lld\t%lld\t%lld\t%.1f\t%lld", s.file.c_str(), s.format.c_str(),
+                     s.type.c_str(), (long long)s.num, (long long)s.len_sum, (long long)s.len_min, s.len_avg,
+                     (long long)s.len_max);
+            out.puts(line);
+            if (o.all) {
+                snprintf(line, sizeof line, "\t%lld\t%lld\t%lld\t%lld\t%lld", (long long)s.q1, (long long)s.q2,
+                         (long long)s.q3, (long long)s.gap_sum, (long long)s.n50);
+                out.puts(line);
+            }
+            out.put('\n');
+        }
+        return 0;
+    }
+    // pretty table (stat.go:211-268): columns padded to their widest cell, numeric columns
+    // right-aligned, two spaces between columns
+    static const char* hdr[13] = {"file", "format", "type", "num_seqs", "sum_len", "min_len", "avg_len",
+                                  "max_len", "Q1", "Q2", "Q3", "sum_gap", "N50"};
+    const size_t ncol = o.all ? 13 : 8;
+    std::vector<std::vector<std::string>> rows;
+    rows.emplace_back(hdr, hdr + ncol);
+    for (const StatInfo& s : infos) {
+        std::vector<std::string> r = {s.file, s.format, s.type, comma(s.num), comma(s.len_sum), comma(s.len_min),
+                                      commaf(s.len_avg), comma(s.len_max)};
+        if (o.all) { r.push_back(comma(s.q1)); r.push_back(comma(s.q2)); r.push_back(comma(s.q3));
+                     r.push_back(comma(s.gap_sum)); r.push_back(comma(s.n50)); }
+        rows.push_back(r);
+    }
+    std::vector<size_t> width(ncol, 0);
+    for (const auto& r : rows) for (size_t c = 0; c < ncol; c++) width[c] = std::max(width[c], r[c].size());
+    for (const auto& r : rows) {
+        for (size_t c = 0; c < ncol; c++) {
+            if (c) out.puts("  ");
+            const size_t pad = width[c] - r[c].size();
+            if (c >= 3) for (size_t i = 0; i < pad; i++) out.put(' ');
+            out.write(r[c].data(), r[c].size());
+            if (c < 3) for (size_t i = 0; i < pad; i++) out.put(' ');
+        }
+        out.put('\n');
+    }
+    return 0;
+}
+
+}  // namespace host

@@ -1,0 +1,171 @@
+// main.cpp -- `seqkit-hip seq|fx2tab|stats [flags] [files...]`: command line of the three
+// reference commands on the hot path (flag names and letters as registered in
+// seqkit/cmd/root.go:65-72, seq.go:291-306, fx2tab.go:157-164, stat.go:292-294).
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "host.h"
+
+using namespace host;
+
+namespace {
+
+struct Flag { const char* s; const char* l; bool takes_value; };
+
+// cobra/pflag syntax: -x, -xyz (bundled booleans), -x VALUE, -xVALUE, --long, --long VALUE, --long=VALUE
+struct Parser {
+    std::vector<Flag> flags;
+    std::vector<std::pair<std::string, std::string>> seen;   // long name -> value ("" for booleans)
+    std::vector<std::string> args;
+    std::string error;
+
+    const Flag* by_short(char c) const { for (auto& f : flags) if (f.s && f.s[0] == c) return &f; return nullptr; }
+    const Flag* by_long(const std::string& n) const { for (auto& f : flags) if (n == f.l) return &f; return nullptr; }
+
+    bool parse(int argc, char** argv, int first)
+    {
+        for (int i = first; i < argc; i++) {
+            std::string a = argv[i];
+            if (a == "--") { for (i++; i < argc; i++) args.push_back(argv[i]); break; }
+            if (a.size() < 2 || a[0] != '-') { args.push_back(a); continue; }
+            if (a[1] == '-') {
+                std::string name = a.substr(2), val;
+                const size_t eq = name.find('=');
+                const bool has_eq = eq != std::string::npos;
+                if (has_eq) { val = name.substr(eq + 1); name = name.substr(0, eq); }
+                const Flag* f = by_long(name);
+                if (!f) { error = "unknown flag: --" + name; return false; }
+                if (f->takes_value && !has_eq) {
+                    if (i + 1 >= argc) { error = "flag needs an argument: --" + name; return false; }
+                    val = argv[++i];
+                }
+                seen.emplace_back(f->l, f->takes_value ? val : (has_eq ? val : "true"));
+                continue;
+            }
+            for (size_t k = 1; k < a.size(); k++) {
+                const Flag* f = by_short(a[k]);
+                if (!f) { error = std::string("unknown shorthand flag: '") + a[k] + "' in " + a; return false; }
+                if (!f->takes_value) { seen.emplace_back(f->l, "true"); continue; }
+                std::string val = a.substr(k + 1);
+                if (!val.empty() && val[0] == '=') val = val.substr(1);
+                if (val.empty()) {
+                    if (i + 1 >= argc) { error = std::string("flag needs an argument: '") + a[k] + "' in " + a; return false; }
+                    val = argv[++i];
+                }
+                seen.emplace_back(f->l, val);
+                break;
+            }
+        }
+        return true;
+    }
+    bool has(const char* l) const { for (auto& kv : seen) if (kv.first == l && kv.second != "false") return true; return false; }
+    std::string value(const char* l, const std::string& dflt) const
+    {
+        std::string v = dflt;
+        for (auto& kv : seen) if (kv.first == l) v = kv.second;
+        return v;
+    }
+    std::vector<std::string> values(const char* l) const     // StringSlice: repeated, comma-separated
+    {
+        std::vector<std::string> out;
+        for (auto& kv : seen) {
+            if (kv.first != l) continue;
+            size_t a = 0;
+            for (;;) {
+                const size_t c = kv.second.find(',', a);
+                out.push_back(kv.second.substr(a, c == std::string::npos ? std::string::npos : c - a));
+                if (c == std::string::npos) break;
+                a = c + 1;
+            }
+        }
+        return out;
+    }
+};
+
+int usage()
+{
+    fprintf(stderr,
+            "seqkit-hip -- SeqKit's seq / fx2tab / stats with the per-record work on an AMD MI355X\n\n"
+            "Usage:\n  seqkit-hip seq    [-r] [-p] [-n] [-s] [-q] [-i] [-m N] [-M N] [global flags] [files...]\n"
+            "  seqkit-hip fx2tab [-l] [-g] [-G] [-B bases]... [-n] [-i] [-H] [-a] [global flags] [files...]\n"
+            "  seqkit-hip stats  [-a] [-T] [-G gap-letters] [global flags] [files...]\n\n"
+            "Global flags: -t/--seq-type dna|rna|protein|unlimit|auto, -j/--threads N, -w/--line-width N,\n"
+            "  -o/--out-file FILE, --quiet, --alphabet-guess-seq-length N, --device N\n");
+    return 255;
+}
+
+}  // namespace
+
+int main(int argc, char** argv)
+{
+    if (argc < 2) return usage();
+    const std::string cmd = argv[1];
+    const bool is_seq = cmd == "seq", is_fx = cmd == "fx2tab", is_st = cmd == "stats" || cmd == "stat";
+    if (!is_seq && !is_fx && !is_st) return usage();
+
+    Parser p;
+    p.flags = {{"t", "seq-type", true}, {"j", "threads", true}, {"w", "line-width", true}, {"o", "out-file", true},
+               {nullptr, "quiet", false}, {nullptr, "alphabet-guess-seq-length", true}, {nullptr, "device", true},
+               {nullptr, "id-regexp", true}, {nullptr, "id-ncbi", false},
+               {nullptr, "batch-bytes", true}, {nullptr, "batch-records", true}};
+    if (is_seq) {
+        const Flag f[] = {{"r", "reverse", false}, {"p", "complement", false}, {"n", "name", false}, {"s", "seq", false},
+                          {"q", "qual", false}, {"i", "only-id", false}, {"m", "min-len", true}, {"M", "max-len", true}};
+        p.flags.insert(p.flags.end(), f, f + 8);
+    } else if (is_fx) {
+        const Flag f[] = {{"l", "length", false}, {"g", "gc", false}, {"G", "gc-skew", false}, {"B", "base-content", true},
+                          {"i", "only-id", false}, {"n", "name", false}, {"H", "header-line", false}, {"a", "alphabet", false}};
+        p.flags.insert(p.flags.end(), f, f + 8);
+    } else {
+        const Flag f[] = {{"T", "tabular", false}, {"G", "gap-letters", true}, {"a", "all", false}};
+        p.flags.insert(p.flags.end(), f, f + 3);
+    }
+    if (!p.parse(argc, argv, 2)) { fprintf(stderr, "Error: %s\n", p.error.c_str()); return 255; }
+
+    GlobalOpts g;
+    std::string t = p.value("seq-type", "auto");
+    for (auto& ch : t) ch = (char)tolower((unsigned char)ch);
+    g.alphabet = t == "dna" ? DNAredundant : t == "rna" ? RNAredundant : t == "protein" ? Protein
+               : t == "unlimit" ? Unlimit : Auto;                         // helper.go:138-156
+    g.threads = atoi(p.value("threads", "2").c_str());
+    if (g.threads <= 0) return fatal("value of flag --threads should be greater than 0");
+    g.line_width = atoi(p.value("line-width", "60").c_str());
+    if (g.line_width < 0) return fatal("value of flag --line-width should be greater than 0");
+    g.out_file = p.value("out-file", "-");
+    g.quiet = p.has("quiet");
+    const long long gl = atoll(p.value("alphabet-guess-seq-length", "10000").c_str());
+    if (gl < 0) return fatal("value of flag --alphabet-guess-seq-length should be greater than 0");
+    if (gl > 0 && gl < 1000) return fatal("value of flag --alphabet-guess-seq-length too small, should >= 1000");
+    g.guess_len = (size_t)gl;
+    g.device = atoi(p.value("device", "0").c_str());
+    g.batch_bytes = strtoull(p.value("batch-bytes", "268435456").c_str(), nullptr, 10);
+    g.batch_records = strtoull(p.value("batch-records", "4194304").c_str(), nullptr, 10);
+    if (p.has("id-regexp") || p.has("id-ncbi"))
+        return fatal("--id-regexp / --id-ncbi are not supported by this driver (default ID rule only)");
+    std::vector<std::string> files = p.args;
+    if (files.empty()) files.push_back("-");                                // helper.go:55-56
+
+    if (is_seq) {
+        SeqOpts o;
+        o.reverse = p.has("reverse"); o.complement = p.has("complement"); o.only_name = p.has("name");
+        o.only_seq = p.has("seq"); o.only_qual = p.has("qual"); o.only_id = p.has("only-id");
+        o.min_len = atoi(p.value("min-len", "-1").c_str());
+        o.max_len = atoi(p.value("max-len", "-1").c_str());
+        if (o.min_len >= 0 && o.max_len >= 0 && o.min_len > o.max_len)
+            return fatal("value of flag -m (--min-len) should be >= value of flag -M (--max-len)");
+        return cmd_seq(g, o, files);
+    }
+    if (is_fx) {
+        Fx2tabOpts o;
+        o.only_id = p.has("only-id"); o.length = p.has("length"); o.gc = p.has("gc"); o.gc_skew = p.has("gc-skew");
+        o.only_name = p.has("name"); o.header_line = p.has("header-line"); o.alphabet_col = p.has("alphabet");
+        o.base = p.values("base-content");
+        return cmd_fx2tab(g, o, files);
+    }
+    StatsOpts o;
+    o.all = p.has("all"); o.tabular = p.has("tabular");
+    o.gap_letters = p.value("gap-letters", "- .");
+    return cmd_stats(g, o, files);
+}

@@ -1,0 +1,108 @@
+"""End-to-end parity of the `seqkit-hip` driver (reader -> CSR batches -> HIP kernels ->
+formatter): its bytes on stdout must equal the reference's documented outputs and the CPU
+oracle's output for the same command line, on every fixture of the reference's tests."""
+import json
+import os
+
+import pytest
+
+from conftest import GOLDEN, ROOT, check_vector, run_cli
+
+pytestmark = pytest.mark.gpu
+
+CLI = os.path.join(ROOT, "seqkit_amd", "seqkit-hip")
+
+with open(os.path.join(GOLDEN, "expected", "manifest.json")) as _fh:
+    _NAMES = sorted(json.load(_fh))
+
+FILES = ["hairpin.fa.gz", "mature.fa.gz", "Illimina1.8.fq.gz", "reads_1.fq.gz", "reads_2.fq.gz", "contigs.fa",
+         "Illimina1.5.fq"]
+
+
+@pytest.fixture(scope="module")
+def cli():
+    assert os.path.exists(CLI), "seqkit-hip is not built (python seqkit_amd/build.py)"
+    return CLI
+
+
+@pytest.mark.parametrize("name", _NAMES)
+def test_documented_vector(cli, manifest, name):
+    check_vector(cli, name, manifest[name])
+
+
+SEQ_VARIANTS = [["-r", "-p"], ["-r"], ["-p"], [], ["-r", "-p", "-w", "0"], ["-rp", "-s"], ["-r", "-p", "-n", "-i"],
+                ["-r", "-p", "-m", "100", "-M", "160"], ["-r", "-p", "-w", "7"]]
+
+
+@pytest.mark.parametrize("f", FILES)
+@pytest.mark.parametrize("flags", SEQ_VARIANTS, ids=lambda v: " ".join(v) or "plain")
+def test_seq_matches_oracle(cli, oracle_cli, f, flags):
+    want = run_cli(oracle_cli, ["seq"] + flags + [f])
+    got = run_cli(cli, ["seq"] + flags + [f])
+    assert got[0] == want[0] == 0 and got[1] == want[1]
+
+
+def test_seq_small_batches_and_qual_only(cli, oracle_cli):
+    # batches of a few records: results must not depend on where the reader cuts them
+    for f in ("reads_1.fq.gz", "hairpin.fa.gz"):
+        want = run_cli(oracle_cli, ["seq", "-r", "-p", f])
+        got = run_cli(cli, ["seq", "-r", "-p", "--batch-records", "7", "--batch-bytes", "1000", f])
+        assert got[1] == want[1]
+    want = run_cli(oracle_cli, ["seq", "-r", "-q", "reads_2.fq.gz"])
+    got = run_cli(cli, ["seq", "-r", "-q", "reads_2.fq.gz"])
+    assert got[0] == 0 and got[1] == want[1]
+    rc, _, err = run_cli(cli, ["seq", "-q", "contigs.fa"])
+    assert rc == 255 and b"[ERRO] FASTA format has no quality" in err
+
+
+FX_VARIANTS = [["-n", "-l", "-g", "-B", "AGCT"], ["-n", "-i", "-l", "-g", "-G", "-H"], ["-l", "-B", "a", "-B", "c", "-B", "ac"],
+               ["-n", "-B", "AACC", "-B", "N", "-B", "-"], ["-n", "-g", "-B", "ACGTURYKMSWBDHVN-."], [],
+               ["-n", "-a", "-l"]]
+
+
+@pytest.mark.parametrize("f", FILES)
+@pytest.mark.parametrize("flags", FX_VARIANTS, ids=lambda v: " ".join(v) or "plain")
+def test_fx2tab_matches_oracle(cli, oracle_cli, f, flags):
+    want = run_cli(oracle_cli, ["fx2tab"] + flags + [f])
+    got = run_cli(cli, ["fx2tab"] + flags + [f])
+    assert got[0] == want[0] == 0 and got[1] == want[1]
+
+
+def test_fx2tab_float_trap(cli):
+    # 34/160 + 33/160 prints 41.87 (two divisions, seqkit/cmd/fx2tab.go:128-133), not 41.88
+    _, out, _ = run_cli(cli, ["fx2tab", "-n", "-i", "-l", "-g", "hairpin.fa.gz"])
+    rows = {l.split(b"\t")[0]: l.split(b"\t") for l in out.splitlines()}
+    assert rows[b"tcc-MIR172b"][3:] == [b"160", b"41.87"] and rows[b"cme-MIR167a"][3:] == [b"160", b"41.87"]
+
+
+@pytest.mark.parametrize("flags", [[], ["-T"], ["-a"], ["-a", "-T"], ["-a", "-G", "N"]], ids=lambda v: " ".join(v) or "plain")
+def test_stats_matches_oracle(cli, oracle_cli, flags):
+    want = run_cli(oracle_cli, ["stats"] + flags + FILES)
+    got = run_cli(cli, ["stats"] + flags + FILES)
+    assert got[0] == want[0] == 0 and got[1] == want[1]
+
+
+def test_stdin_edge_cases(cli, oracle_cli):
+    cases = [">a\nATAT\n>b\n>c\nGGC\n", ">s\nAC-GT..A C\n", ">x\nacgtnACGTN\n", "@r\nAACGN\n+\n!#%&(\n",
+             ">only\n", ">a\r\nAC\r\nGT\r\n>b\r\nTTTT", ">e1\n>e2\n>e3\nA\n"]
+    for text in cases:
+        for argv in (["seq", "-r", "-p"], ["fx2tab", "-n", "-l", "-g", "-G", "-B", "AT"], ["stats", "-a", "-T"]):
+            want = run_cli(oracle_cli, argv, stdin=text)
+            got = run_cli(cli, argv, stdin=text)
+            assert got[0] == want[0] and got[1] == want[1], (text, argv)
+
+
+def test_long_records_through_the_driver(cli, oracle_cli, tmp_path):
+    import numpy as np
+    rng = np.random.default_rng(5)
+    p = tmp_path / "long.fa"
+    with open(p, "wb") as fh:
+        for i, n in enumerate([100000, 33, 1 << 20, 5, 250001]):
+            s = rng.choice(np.frombuffer(b"ACGTNacgtn", np.uint8), size=n).tobytes()
+            fh.write(b">r%d\n" % i)
+            for a in range(0, n, 70):
+                fh.write(s[a:a + 70] + b"\n")
+    for argv in (["seq", "-r", "-p", str(p)], ["fx2tab", "-n", "-l", "-g", "-B", "AT", str(p)], ["stats", "-a", str(p)]):
+        want = run_cli(oracle_cli, argv)
+        got = run_cli(cli, argv)
+        assert got[0] == want[0] == 0 and got[1] == want[1]
