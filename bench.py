@@ -196,12 +196,11 @@ def main():
     stats_ms = (time.perf_counter() - ts) * 1e3
     allreduce_us = None
     if world > 1:
-        sums, mx = stats_d[:3].clone(), torch.stack([stats_d[4], -stats_d[3]])
+        from seqkit_amd import shard
         torch.cuda.synchronize(); ta = time.perf_counter()
-        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        tot = shard.allreduce_stats(stats_d)              # the path's only collective (RCCL)
         torch.cuda.synchronize(); allreduce_us = (time.perf_counter() - ta) * 1e6
-        stats = [int(sums[0]), int(sums[1]), int(sums[2]), int(-mx[1]), int(mx[0])]
+        stats = [int(x) for x in tot.cpu()]
     else:
         stats = [int(x) for x in stats_d.cpu()]
     assert stats[:2] == [nrec * world, total * world] and stats[3:] == [L, L], stats

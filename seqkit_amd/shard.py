@@ -1,0 +1,53 @@
+"""Multi-GPU decomposition of the hot path (one process per GPU).
+
+Records are independent, so a batch is cut into contiguous record ranges of about equal BYTE
+volume, one per rank; reverse-complement and per-record counts then need no exchange at all
+(each rank's outputs are a contiguous slice of the result).  A record longer than a rank's
+share is cut INSIDE the record: input slice [a, b) of a record of length L is itself a record
+whose reverse-complement lands at [L-b, L-a) of the result, so slices are independent too.
+The only collective of the path is the element-wise reduction of the five `stats` totals
+(seqkit/cmd/stat.go:106-125): sum for num / len_sum / gap_sum, min / max for the extremes.
+"""
+import numpy as np
+
+
+def split_by_bytes(offsets, nparts):
+    """Contiguous record ranges [(lo, hi)) * nparts with byte volumes as equal as record
+    boundaries allow (greedy prefix split of the CSR offsets)."""
+    offsets = np.asarray(offsets, dtype=np.uint64)
+    nrec = len(offsets) - 1
+    total = int(offsets[-1])
+    cuts = [0]
+    for k in range(1, nparts):
+        target = total * k // nparts
+        r = int(np.searchsorted(offsets, np.uint64(target), side="left"))
+        # nearer of the two record boundaries around the byte target
+        if r > 0 and r <= nrec and abs(int(offsets[r - 1]) - target) <= abs(int(offsets[min(r, nrec)]) - target):
+            r -= 1
+        cuts.append(min(max(r, cuts[-1]), nrec))
+    cuts.append(nrec)
+    return [(cuts[i], cuts[i + 1]) for i in range(nparts)]
+
+
+def split_record(length, nparts, align=16):
+    """Cuts one long record into `nparts` slices at `align`-byte multiples.
+    Returns [(a, b, out_pos)]: input slice [a, b) and where its reverse goes in the output."""
+    cuts = [0]
+    for k in range(1, nparts):
+        c = (length * k // nparts) // align * align
+        cuts.append(max(c, cuts[-1]))
+    cuts.append(length)
+    return [(cuts[i], cuts[i + 1], length - cuts[i + 1]) for i in range(nparts)]
+
+
+def allreduce_stats(partial, group=None):
+    """partial: int64 tensor [num, len_sum, gap_sum, len_min, len_max] of this rank (layout of
+    skh_stats_partial).  Returns the file-level totals on every rank: two small all-reduces
+    (RCCL on GPUs, gloo on CPU)."""
+    import torch
+    import torch.distributed as dist
+    sums = partial[:3].clone()
+    ext = torch.stack([partial[4], -partial[3]])          # max(len_max), max(-len_min)
+    dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+    dist.all_reduce(ext, op=dist.ReduceOp.MAX, group=group)
+    return torch.stack([sums[0], sums[1], sums[2], -ext[1], ext[0]])
