@@ -53,7 +53,8 @@ struct skh_ctx {
     hipStream_t stream = nullptr;
     uint32_t* d_flags = nullptr;           // ring of "long records seen" words
     std::atomic<uint32_t> flag_next{0};
-    uint32_t max_grid = 2048;
+    uint32_t max_grid = 0;
+    uint32_t n_cu = 256;
     int force_logG = -1;
     int span_u = 4;
     int fuse_fastq = 0;
@@ -82,6 +83,7 @@ skh::LaunchCfg cfg_for(const skh_ctx* ctx, uint64_t nrec, uint64_t total)
 {
     skh::LaunchCfg c;
     c.max_grid = ctx->max_grid;
+    c.n_cu = ctx->n_cu;
     c.span_u = ctx->span_u;
     c.fuse_fastq = ctx->fuse_fastq;
     if (ctx->force_logG >= 0) {
@@ -134,8 +136,8 @@ int skh_init(int device, skh_ctx** out)
     skh_ctx* c = new (std::nothrow) skh_ctx;
     if (!c) return fail(SKH_ENOMEM, "out of host memory");
     c->device = device;
-    c->max_grid = (uint32_t)env_int("SKH_MAX_GRID", prop.multiProcessorCount * 8);
-    if (c->max_grid < 1) c->max_grid = 1;
+    c->max_grid = (uint32_t)env_int("SKH_MAX_GRID", 0);
+    c->n_cu = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256u;
     c->force_logG = env_int("SKH_LOGG", -1);
     c->span_u = env_int("SKH_SPAN_U", 0);
     c->fuse_fastq = env_int("SKH_FUSE_FASTQ", 0);

@@ -15,7 +15,8 @@ struct StatsPartial { int64_t num, len_sum, gap_sum, len_min, len_max; };
 
 struct LaunchCfg {
     int logG;            // log2 of lanes per record in the short kernels (0..6)
-    uint32_t max_grid;   // cap on workgroups of a grid-stride launch
+    uint32_t max_grid;   // optional cap on workgroups of a grid-stride launch (0 = none)
+    uint32_t n_cu;       // compute units of the device
     int fuse_fastq;      // reverse: 1 = bases and qualities in one launch, 0 = one launch per plane
     int span_u;          // reverse: 0 = lane-group kernels, 2 or 4 = span kernel with that many chunks per lane
 };

@@ -22,6 +22,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+#include <unordered_map>
+
 #include "kernels.h"
 
 namespace skh {
@@ -67,6 +70,39 @@ __device__ __forceinline__ uint64_t find_record(const uint64_t* __restrict__ off
     }
     return lo;
 }
+
+// Offsets of the GW consecutive records a wavefront serves in one step of the short
+// kernels, fetched by ONE load instruction with GW+2 active lanes (lane l holds
+// offs[rec0 - 1 + l]) and handed to the lane groups by cross-lane reads.  Letting every lane
+// load its record's two or three offsets instead costs the texture addresser as much as
+// the sequence data of a 150-base read.  Indices outside [0, nrec] read as 0 / total, so
+// records past the end look empty.  Call from wave-uniform control flow only.
+struct WaveOffsets {
+    uint64_t v0, v1;
+    __device__ __forceinline__ static uint64_t at(const uint64_t* __restrict__ offs, uint64_t nrec,
+                                                  uint64_t total, uint64_t rec0, uint32_t l)
+    {
+        if (rec0 == 0 && l == 0) return 0;
+        const uint64_t idx = rec0 - 1 + l;
+        return idx > nrec ? total : offs[idx];
+    }
+    __device__ __forceinline__ void load(const uint64_t* __restrict__ offs, uint64_t nrec, uint64_t total,
+                                         uint64_t rec0, uint32_t GW, uint32_t lane)
+    {
+        v0 = 0;
+        v1 = 0;
+        if (lane <= GW + 1) v0 = at(offs, nrec, total, rec0, lane);
+        if (GW == 64 && lane < 2) v1 = at(offs, nrec, total, rec0, 64 + lane);
+    }
+    // value number k (0 = offs[rec0-1]); GW is wave-uniform
+    __device__ __forceinline__ uint64_t get(uint32_t k, uint32_t GW) const
+    {
+        const uint64_t a = __shfl(v0, (int)(k & 63));
+        if (GW != 64) return a;
+        const uint64_t b = __shfl(v1, (int)(k & 63));
+        return k < 64 ? a : b;
+    }
+};
 
 // ------------------------------------------------------------------ reverse (+complement)
 //
@@ -331,16 +367,20 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_reverse_short(RevPlanes P, uint64
     rev_lds_init<COMP>(L, lut);
     constexpr int U = 3;
     const uint32_t G = 1u << logG, j = threadIdx.x & (G - 1);
-    const uint64_t per_block = SKH_BLOCK >> logG;
-    const uint64_t stride = (uint64_t)gridDim.x * per_block;
-    uint64_t rec = (uint64_t)xcd_remap(blockIdx.x, gridDim.x) * per_block + (threadIdx.x >> logG);
-    if (rec >= nrec) return;
-    uint64_t sprev = rec ? P.offs[rec - 1] : 0, s = P.offs[rec], e = P.offs[rec + 1];
+    const uint32_t lane = threadIdx.x & 63, GW = 64u >> logG, g = lane >> logG;
+    const uint64_t stride = (uint64_t)gridDim.x * (SKH_BLOCK / 64) * GW;
+    // the wavefront's first record; all its lanes run the same number of steps
+    uint64_t rec0 = ((uint64_t)xcd_remap(blockIdx.x, gridDim.x) * (SKH_BLOCK / 64) + (threadIdx.x >> 6)) * GW;
+    if (rec0 >= nrec) return;
+    WaveOffsets wo;
+    wo.load(P.offs, nrec, P.total, rec0, GW, lane);
     while (true) {
-        // offsets of the next record of this group are requested before this one is worked on
-        const uint64_t next = rec + stride;
-        uint64_t nsprev = 0, ns = 0, ne = 0;
-        if (next < nrec) { nsprev = P.offs[next - 1]; ns = P.offs[next]; ne = P.offs[next + 1]; }
+        // the offsets of the next step are requested before this one is worked on
+        const uint64_t next0 = rec0 + stride;
+        WaveOffsets nwo;
+        if (next0 < nrec) nwo.load(P.offs, nrec, P.total, next0, GW, lane);
+        const uint64_t rec = rec0 + g;
+        const uint64_t sprev = wo.get(g, GW), s = wo.get(g + 1, GW), e = wo.get(g + 2, GW);
         const uint64_t len = e - s;
         if (len > SKH_LONG_T) {
             if (j == 0) atomicAdd(n_long, 1u);
@@ -353,8 +393,9 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_reverse_short(RevPlanes P, uint64
                 reverse_chunk_generic<COMP, FASTQ>(P.in, P.out, P.qin, P.qout, P.offs, rec, P.total,
                                                    o0 + 16ull * n_own, L.lut);
         }
-        if (next >= nrec) break;
-        rec = next; sprev = nsprev; s = ns; e = ne;
+        if (next0 >= nrec) break;
+        rec0 = next0;
+        wo = nwo;
     }
 }
 
@@ -417,7 +458,7 @@ struct SpanLds {
     uint64_t cursor;              // owner of the span's last chunk, seeds the next span
 };
 
-template <bool COMP, bool FASTQ, int U>
+template <bool COMP, int U>
 __global__ __launch_bounds__(SKH_BLOCK) void k_reverse_span(RevPlanes P, uint64_t nrec, Table256 lut)
 {
     __shared__ SpanLds S;
@@ -472,22 +513,27 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_reverse_span(RevPlanes P, uint64_
             const uint64_t pl = B0 + 15 < total ? B0 + 15 : total - 1;
             const uint64_t r = find_record(P.offs, nrec, pl);
             if (tid == 0)
-                reverse_chunk_generic<COMP, FASTQ>(P.in, P.out, P.qin, P.qout, P.offs, r, total, B0, S.tab.lut);
+                reverse_chunk_generic<COMP, false>(P.in, P.out, nullptr, nullptr, P.offs, r, total, B0, S.tab.lut);
             __syncthreads();
             r_cur = r;
             c_next += 1;
             continue;
         }
 
-        // ---- per chunk: owner search, window addresses, loads (all issued before first use)
-        uint4 W[U], Q[U], HP[U], HQ[U];
-        uint32_t kind[U];         // 0 none, 1 interior, 2 head (two windows), 3 generic; bits 8.. = sp
-        uint64_t own[U];
+        // ---- per chunk: owner search, then the aligned source chunk (all loads before first use).
+        // meta: bits 0-1 kind (0 none, 1 interior, 2 head, 3 generic), 2-5 window offset dq,
+        //       6-9 sp (bytes of a head chunk before its owner), 10.. owner's index in S.off
+        uint4 W[U], E[U], HP[U];
+        uint32_t meta[U];
+        uint64_t alo[U];
+        const uint32_t lane = tid & 63;
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const uint32_t c = tid + u * SKH_BLOCK;
-            kind[u] = 0;
-            own[u] = 0;
+            meta[u] = 0;
+            alo[u] = 0;
+            W[u] = make_uint4(0, 0, 0, 0);
+            HP[u] = make_uint4(0, 0, 0, 0);
             if (c < nc) {
                 const uint64_t o = B0 + 16ull * c;
                 const int32_t p_rel = (o + 15 < total ? 16 * (int32_t)c + 15 : (int32_t)(total - 1 - B0));
@@ -496,47 +542,53 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_reverse_span(RevPlanes P, uint64_
                     if (S.rel[i + step] <= p_rel) i += step;
                 const uint64_t s = S.off[i], e = S.off[i + 1];
                 const uint64_t sprev = i ? S.off[i - 1] : 0;
-                own[u] = a + i;
                 const uint64_t q = s + e - 16 - o;
+                const uint32_t dq = (uint32_t)q & 15u;
+                alo[u] = q - dq;
+                uint32_t kind = 3, sp = 0;
                 if (o + 16 > total) {
-                    kind[u] = 3;                                  // the chunk straddling the plane end
+                    kind = 3;                                     // the chunk straddling the plane end
                 } else if (o >= s) {
-                    kind[u] = 1;
-                    W[u] = ldu16(P.in + q);
-                    if (FASTQ) Q[u] = ldu16(P.qin + q);
+                    kind = 1;
+                    W[u] = ld16(P.in + alo[u]);
                 } else {
-                    const uint32_t sp = (uint32_t)(s - o);        // bytes of the chunk before the owner
-                    if (sprev <= o && sprev + sp >= 16 && e + sp <= padded) {
-                        kind[u] = 2 | (sp << 8);
-                        const uint64_t qp = sprev + s - 16 - o;   // window of the previous record
-                        W[u] = ldu16(P.in + q);
-                        HP[u] = ldu16(P.in + qp);
-                        if (FASTQ) { Q[u] = ldu16(P.qin + q); HQ[u] = ldu16(P.qin + qp); }
-                    } else {
-                        kind[u] = 3;
+                    sp = (uint32_t)(s - o);                       // bytes of the chunk before the owner
+                    if (sprev <= o && sprev + sp >= 16) {
+                        kind = 2;
+                        W[u] = ld16(P.in + alo[u]);
+                        HP[u] = ldu16(P.in + (sprev + s - 16 - o));   // window in the previous record
                     }
                 }
+                meta[u] = kind | (dq << 2) | (sp << 6) | (i << 10);
                 if (c == nc - 1) S.cursor = a + i;
             }
         }
+        // The chunk a window spills into is the aligned chunk of the lane before, when that lane
+        // serves the previous chunk of the same record; otherwise it is loaded here.
+        bool own_upper[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const uint32_t k = kind[u] & 0xffu;
+            const uint32_t nbm = __shfl(meta[u], (int)lane - 1);
+            const uint32_t kind = meta[u] & 3u, nbk = nbm & 3u;
+            const bool same = lane != 0 && (nbk == 1 || nbk == 2) && (nbm >> 10) == (meta[u] >> 10);
+            own_upper[u] = (kind == 1 || kind == 2) && ((meta[u] >> 2) & 15u) != 0 && !same;
+            E[u] = make_uint4(0, 0, 0, 0);
+            if (own_upper[u] && alo[u] + 32 <= padded) E[u] = ld16(P.in + alo[u] + 16);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t kind = meta[u] & 3u, dq = (meta[u] >> 2) & 15u, sp = (meta[u] >> 6) & 15u;
             const uint64_t o = B0 + 16ull * (tid + u * SKH_BLOCK);
-            if (k == 3) {
-                reverse_chunk_generic<COMP, FASTQ>(P.in, P.out, P.qin, P.qout, P.offs, own[u], total, o, S.tab.lut);
-            } else if (k != 0) {
-                uint4 r = reverse16(W[u]), rq;
-                if (FASTQ) rq = reverse16(Q[u]);
-                if (k == 2) {
-                    const uint4 m = S.tab.low[kind[u] >> 8];
-                    r = select16(m, reverse16(HP[u]), r);
-                    if (FASTQ) rq = select16(m, reverse16(HQ[u]), rq);
-                }
-                if (COMP) r = map16(r, S.tab.lut);
+            uint4 n = shfl16(W[u], (int)lane - 1);          // cross-lane: every lane, no divergence
+            if (own_upper[u]) n = E[u];
+            uint4 r = window_reversed(W[u], n, dq);
+            if (kind == 2) r = select16(S.tab.low[sp], reverse16(HP[u]), r);
+            if (COMP) r = map16(r, S.tab.lut);
+            if (kind == 3)
+                reverse_chunk_generic<COMP, false>(P.in, P.out, nullptr, nullptr, P.offs, a + (meta[u] >> 10), total, o,
+                                                   S.tab.lut);
+            else if (kind != 0)
                 *reinterpret_cast<uint4*>(P.out + o) = r;
-                if (FASTQ) *reinterpret_cast<uint4*>(P.qout + o) = rq;
-            }
         }
         __syncthreads();                     // S.off / S.rel are rewritten by the next span
         r_cur = S.cursor;
@@ -618,11 +670,10 @@ __device__ __forceinline__ void count4(uint32_t w, const uint32_t* lut, uint32_t
 // boundary chunk outside the record are replaced by it before the table lookup.
 // Without such a byte (every value classified) they are skipped one by one.
 template <int NW>
-__device__ __forceinline__ void count_chunk(const uint8_t* __restrict__ seq, uint64_t s, uint64_t e,
-                                            uint64_t o, const CountLds<NW>& L, uint32_t neutral4,
-                                            bool has_neutral, uint32_t* acc8)
+__device__ __forceinline__ void count_loaded(uint4 v, uint64_t s, uint64_t e, uint64_t o,
+                                             const CountLds<NW>& L, uint32_t neutral4, bool has_neutral,
+                                             uint32_t* acc8)
 {
-    uint4 v = ld16(seq + o);
     if (o < s || o + 16 > e) {
         const int lo = s > o ? (int)(s - o) : 0;
         const int hi = e < o + 16 ? (int)(e - o) : 16;
@@ -649,6 +700,14 @@ __device__ __forceinline__ void count_chunk(const uint8_t* __restrict__ seq, uin
     count4<NW>(v.y, L.lut, acc8);
     count4<NW>(v.z, L.lut, acc8);
     count4<NW>(v.w, L.lut, acc8);
+}
+
+template <int NW>
+__device__ __forceinline__ void count_chunk(const uint8_t* __restrict__ seq, uint64_t s, uint64_t e,
+                                            uint64_t o, const CountLds<NW>& L, uint32_t neutral4,
+                                            bool has_neutral, uint32_t* acc8)
+{
+    count_loaded<NW>(ld16(seq + o), s, e, o, L, neutral4, has_neutral, acc8);
 }
 
 // 8-bit fields -> 16-bit fields: acc16[2w] takes classes 4w+0 and 4w+2, acc16[2w+1]
@@ -679,22 +738,29 @@ __device__ __forceinline__ uint32_t field16(const uint32_t* acc16, uint32_t c)
 
 template <int NW>
 __global__ __launch_bounds__(SKH_BLOCK) void k_count_short(
-    const uint8_t* __restrict__ seq, const uint64_t* __restrict__ offs, uint64_t nrec, Table256 cls,
-    uint32_t nclass, int logG, uint32_t neutral, uint64_t* __restrict__ counts,
+    const uint8_t* __restrict__ seq, const uint64_t* __restrict__ offs, uint64_t nrec, uint64_t total,
+    Table256 cls, uint32_t nclass, int logG, uint32_t neutral, uint64_t* __restrict__ counts,
     uint32_t* __restrict__ n_long)
 {
     __shared__ CountLds<NW> L;
     count_lds_init<NW>(L, cls);
+    constexpr int U = 3;
     const bool has_neutral = neutral < 256u;
     const uint32_t neutral4 = (neutral & 0xffu) * 0x01010101u;
     const uint32_t G = 1u << logG, j = threadIdx.x & (G - 1);
-    const uint64_t per_block = SKH_BLOCK >> logG;
-    const uint64_t stride = (uint64_t)gridDim.x * per_block;
-    // every lane of a group must stay in the loop for the cross-lane sum: the bound
-    // is on the group's record, identical for its lanes; whole groups drop out together
-    uint64_t rec = (uint64_t)xcd_remap(blockIdx.x, gridDim.x) * per_block + (threadIdx.x >> logG);
-    for (; rec < nrec; rec += stride) {
-        const uint64_t s = offs[rec], e = offs[rec + 1];
+    const uint32_t lane = threadIdx.x & 63, GW = 64u >> logG, g = lane >> logG;
+    const uint64_t stride = (uint64_t)gridDim.x * (SKH_BLOCK / 64) * GW;
+    // the wavefront's first record; all its lanes run the same number of steps
+    uint64_t rec0 = ((uint64_t)xcd_remap(blockIdx.x, gridDim.x) * (SKH_BLOCK / 64) + (threadIdx.x >> 6)) * GW;
+    if (rec0 >= nrec) return;
+    WaveOffsets wo;
+    wo.load(offs, nrec, total, rec0, GW, lane);
+    while (true) {
+        const uint64_t next0 = rec0 + stride;
+        WaveOffsets nwo;
+        if (next0 < nrec) nwo.load(offs, nrec, total, next0, GW, lane);
+        const uint64_t rec = rec0 + g;
+        const uint64_t s = wo.get(g + 1, GW), e = wo.get(g + 2, GW);
         const uint64_t len = e - s;
         uint32_t acc16[2 * NW];
 #pragma unroll
@@ -708,11 +774,23 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_count_short(
             const uint64_t o0 = s & ~15ull;
             const uint32_t K = (uint32_t)((e - o0 + 15) >> 4);
             uint32_t pending = 0;
-            for (uint32_t k = j; k < K; k += G) {
-                count_chunk<NW>(seq, s, e, o0 + 16ull * k, L, neutral4, has_neutral, acc8);
-                if (++pending == 15) {       // 15 chunks * 16 bytes = 240 < 256 per field
-                    widen<NW>(acc8, acc16);
-                    pending = 0;
+            for (uint32_t kb = 0; kb < K; kb += U * G) {
+                uint4 V[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {            // all loads of the step before the first use:
+                    const uint32_t k = kb + j + u * G;   // unconditional (a lane without a chunk re-reads
+                    V[u] = ld16(seq + o0 + 16ull * (k < K ? k : 0));   // chunk 0) so they issue back to back
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const uint32_t k = kb + j + u * G;
+                    if (k < K) {
+                        count_loaded<NW>(V[u], s, e, o0 + 16ull * k, L, neutral4, has_neutral, acc8);
+                        if (++pending == 15) {           // 15 chunks * 16 bytes = 240 < 256 per field
+                            widen<NW>(acc8, acc16);
+                            pending = 0;
+                        }
+                    }
                 }
             }
             widen<NW>(acc8, acc16);
@@ -722,8 +800,11 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_count_short(
                 for (int i = 0; i < 2 * NW; i++) acc16[i] += __shfl_xor(acc16[i], m);
             }
         }
-        for (uint32_t c = j; c < nclass; c += G)
-            counts[rec * nclass + c] = field16<NW>(acc16, c);
+        if (rec < nrec)
+            for (uint32_t c = j; c < nclass; c += G) counts[rec * nclass + c] = field16<NW>(acc16, c);
+        if (next0 >= nrec) break;
+        rec0 = next0;
+        wo = nwo;
     }
 }
 
@@ -863,17 +944,43 @@ static inline uint32_t grid_for(uint64_t work_items, uint64_t per_block, uint32_
     return (uint32_t)g;
 }
 
-template <bool COMP, bool FASTQ>
+// Grid cap of a grid-stride kernel: exactly the workgroups the chip holds at once (CUs x
+// resident workgroups per CU).  The kernels split their work statically over the grid, so
+// one workgroup more per CU than fits would run as a second, nearly empty round.
+template <typename K>
+static uint32_t resident_cap(K kernel, const LaunchCfg& cfg)
+{
+    static std::mutex mu;
+    static std::unordered_map<const void*, int> cache;
+    const void* key = reinterpret_cast<const void*>(kernel);
+    int occ;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        auto it = cache.find(key);
+        if (it == cache.end()) {
+            int o = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, kernel, SKH_BLOCK, 0) != hipSuccess || o < 1) o = 4;
+            if (o > 8) o = 8;
+            it = cache.emplace(key, o).first;
+        }
+        occ = it->second;
+    }
+    uint64_t g = (uint64_t)cfg.n_cu * (uint64_t)occ;
+    if (cfg.max_grid && g > cfg.max_grid) g = cfg.max_grid;
+    return (uint32_t)(g ? g : 1);
+}
+
+template <bool COMP>
 static hipError_t launch_reverse_span_t(const LaunchCfg& cfg, const RevPlanes& P, uint64_t nrec,
                                         const Table256& lut, hipStream_t st)
 {
     const uint64_t nch = (P.total + 15) >> 4;
     if (cfg.span_u == 2) {
-        const uint32_t g = grid_for(nch, 2 * SKH_BLOCK, cfg.max_grid);
-        hipLaunchKernelGGL((k_reverse_span<COMP, FASTQ, 2>), dim3(g), dim3(SKH_BLOCK), 0, st, P, nrec, lut);
+        const uint32_t g = grid_for(nch, 2 * SKH_BLOCK, resident_cap(k_reverse_span<COMP, 2>, cfg));
+        hipLaunchKernelGGL((k_reverse_span<COMP, 2>), dim3(g), dim3(SKH_BLOCK), 0, st, P, nrec, lut);
     } else {
-        const uint32_t g = grid_for(nch, 4 * SKH_BLOCK, cfg.max_grid);
-        hipLaunchKernelGGL((k_reverse_span<COMP, FASTQ, 4>), dim3(g), dim3(SKH_BLOCK), 0, st, P, nrec, lut);
+        const uint32_t g = grid_for(nch, 4 * SKH_BLOCK, resident_cap(k_reverse_span<COMP, 4>, cfg));
+        hipLaunchKernelGGL((k_reverse_span<COMP, 4>), dim3(g), dim3(SKH_BLOCK), 0, st, P, nrec, lut);
     }
     return hipGetLastError();
 }
@@ -885,11 +992,11 @@ static hipError_t launch_reverse_t(const LaunchCfg& cfg, const uint8_t* in, uint
                                    uint32_t* n_long, hipStream_t st)
 {
     const RevPlanes P{in, out, qin, qout, offs, total};
-    if (cfg.span_u) return launch_reverse_span_t<COMP, FASTQ>(cfg, P, nrec, lut, st);
-    const uint32_t g1 = grid_for(nrec, SKH_BLOCK >> cfg.logG, cfg.max_grid);
+    if (cfg.span_u && !FASTQ) return launch_reverse_span_t<COMP>(cfg, P, nrec, lut, st);
+    const uint32_t g1 = grid_for(nrec, SKH_BLOCK >> cfg.logG, resident_cap(k_reverse_short<COMP, FASTQ>, cfg));
     hipLaunchKernelGGL((k_reverse_short<COMP, FASTQ>), dim3(g1), dim3(SKH_BLOCK), 0, st, P, nrec, lut,
                        cfg.logG, n_long);
-    const uint32_t g2 = grid_for((total + SKH_TILE - 1) / SKH_TILE, 1, cfg.max_grid);
+    const uint32_t g2 = grid_for((total + SKH_TILE - 1) / SKH_TILE, 1, resident_cap(k_reverse_tiles<COMP, FASTQ>, cfg));
     hipLaunchKernelGGL((k_reverse_tiles<COMP, FASTQ>), dim3(g2), dim3(SKH_BLOCK), 0, st, P, nrec, lut,
                        n_long);
     return hipGetLastError();
@@ -901,7 +1008,7 @@ hipError_t launch_reverse(const LaunchCfg& cfg, const uint8_t* in, uint8_t* out,
 {
     static const Table256 ident = [] { Table256 t; for (int i = 0; i < 256; i++) t.v[i] = (uint8_t)i; return t; }();
     bool fastq = qin != nullptr;
-    if (fastq && !cfg.fuse_fastq) {
+    if (fastq && (!cfg.fuse_fastq || cfg.span_u)) {
         // the two planes as two launches: half the registers per lane, twice the resident
         // wavefronts; the offsets are read twice, which is cheaper than the lost occupancy
         hipError_t e = launch_reverse(cfg, qin, qout, nullptr, nullptr, offs, nrec, total, nullptr, n_long, st);
@@ -921,7 +1028,7 @@ hipError_t launch_reverse(const LaunchCfg& cfg, const uint8_t* in, uint8_t* out,
 hipError_t launch_map_plane(const LaunchCfg& cfg, const uint8_t* in, uint8_t* out, uint64_t total,
                             const Table256& lut, hipStream_t st)
 {
-    const uint32_t g = grid_for((total + 15) >> 4, SKH_BLOCK, cfg.max_grid);
+    const uint32_t g = grid_for((total + 15) >> 4, SKH_BLOCK, resident_cap(k_map_plane, cfg));
     hipLaunchKernelGGL(k_map_plane, dim3(g), dim3(SKH_BLOCK), 0, st, in, out, total, lut);
     return hipGetLastError();
 }
@@ -930,15 +1037,18 @@ hipError_t launch_count(const LaunchCfg& cfg, const uint8_t* seq, const uint64_t
                         uint64_t total, const Table256& cls, uint32_t nclass, uint32_t neutral,
                         uint64_t* counts, uint32_t* n_long, hipStream_t st)
 {
-    const uint32_t g1 = grid_for(nrec, SKH_BLOCK >> cfg.logG, cfg.max_grid);
-    const uint32_t g2 = grid_for((total + SKH_TILE - 1) / SKH_TILE, 1, cfg.max_grid);
+    const uint64_t ntile = (total + SKH_TILE - 1) / SKH_TILE;
     if (nclass <= 4) {
-        hipLaunchKernelGGL((k_count_short<1>), dim3(g1), dim3(SKH_BLOCK), 0, st, seq, offs, nrec, cls,
+        const uint32_t g1 = grid_for(nrec, SKH_BLOCK >> cfg.logG, resident_cap(k_count_short<1>, cfg));
+        const uint32_t g2 = grid_for(ntile, 1, resident_cap(k_count_tiles<1>, cfg));
+        hipLaunchKernelGGL((k_count_short<1>), dim3(g1), dim3(SKH_BLOCK), 0, st, seq, offs, nrec, total, cls,
                            nclass, cfg.logG, neutral, counts, n_long);
         hipLaunchKernelGGL((k_count_tiles<1>), dim3(g2), dim3(SKH_BLOCK), 0, st, seq, offs, nrec, total,
                            cls, nclass, neutral, counts, n_long);
     } else {
-        hipLaunchKernelGGL((k_count_short<2>), dim3(g1), dim3(SKH_BLOCK), 0, st, seq, offs, nrec, cls,
+        const uint32_t g1 = grid_for(nrec, SKH_BLOCK >> cfg.logG, resident_cap(k_count_short<2>, cfg));
+        const uint32_t g2 = grid_for(ntile, 1, resident_cap(k_count_tiles<2>, cfg));
+        hipLaunchKernelGGL((k_count_short<2>), dim3(g1), dim3(SKH_BLOCK), 0, st, seq, offs, nrec, total, cls,
                            nclass, cfg.logG, neutral, counts, n_long);
         hipLaunchKernelGGL((k_count_tiles<2>), dim3(g2), dim3(SKH_BLOCK), 0, st, seq, offs, nrec, total,
                            cls, nclass, neutral, counts, n_long);
@@ -951,7 +1061,7 @@ hipError_t launch_stats(const LaunchCfg& cfg, const uint8_t* seq, const uint64_t
 {
     hipLaunchKernelGGL(k_stats_init, dim3(1), dim3(1), 0, st, out, nrec, total);
     const uint64_t items = ((total + 15) >> 4) > nrec ? ((total + 15) >> 4) : nrec;
-    const uint32_t g = grid_for(items, SKH_BLOCK, cfg.max_grid);
+    const uint32_t g = grid_for(items, SKH_BLOCK, resident_cap(k_stats, cfg));
     hipLaunchKernelGGL(k_stats, dim3(g), dim3(SKH_BLOCK), 0, st, seq, offs, nrec, total, is_gap, out);
     return hipGetLastError();
 }
