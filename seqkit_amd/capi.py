@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libseqkit_hip.so")
+LIB_PATH = os.environ.get("SKH_LIB") or os.path.join(HERE, "libseqkit_hip.so")
 
 MAX_CLASSES = 8
 NO_CLASS = 0xFF

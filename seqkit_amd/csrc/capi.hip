@@ -58,6 +58,7 @@ struct skh_ctx {
     int force_logG = -1;
     int span_u = 4;
     int fuse_fastq = 0;
+    int staged = 1;
 };
 
 struct skh_batch {
@@ -86,6 +87,7 @@ skh::LaunchCfg cfg_for(const skh_ctx* ctx, uint64_t nrec, uint64_t total)
     c.n_cu = ctx->n_cu;
     c.span_u = ctx->span_u;
     c.fuse_fastq = ctx->fuse_fastq;
+    c.staged = ctx->staged;
     if (ctx->force_logG >= 0) {
         c.logG = ctx->force_logG > 6 ? 6 : ctx->force_logG;
         return c;
@@ -141,6 +143,7 @@ int skh_init(int device, skh_ctx** out)
     c->force_logG = env_int("SKH_LOGG", -1);
     c->span_u = env_int("SKH_SPAN_U", 0);
     c->fuse_fastq = env_int("SKH_FUSE_FASTQ", 0);
+    c->staged = env_int("SKH_STAGED", 1);
     e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->d_flags), N_FLAGS * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemset(c->d_flags, 0, N_FLAGS * sizeof(uint32_t));

@@ -17,6 +17,7 @@ struct LaunchCfg {
     int logG;            // log2 of lanes per record in the short kernels (0..6)
     uint32_t max_grid;   // optional cap on workgroups of a grid-stride launch (0 = none)
     uint32_t n_cu;       // compute units of the device
+    int staged;          // reverse, short records: 1 = LDS-staged kernel, 0 = direct (lane exchange) kernel
     int fuse_fastq;      // reverse: 1 = bases and qualities in one launch, 0 = one launch per plane
     int span_u;          // reverse: 0 = lane-group kernels, 2 or 4 = span kernel with that many chunks per lane
 };

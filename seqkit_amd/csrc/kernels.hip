@@ -37,6 +37,9 @@ namespace skh {
 // meet in the same L2.  Speed only; any mapping is correct.
 __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n)
 {
+#ifdef SKH_NO_XCD_REMAP
+    return b;
+#endif
     const uint32_t q = n >> 3, r = n & 7, x = b & 7, k = b >> 3;
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
 }
@@ -199,10 +202,9 @@ __device__ __forceinline__ void store_clipped(uint8_t* __restrict__ out, uint64_
 // looked up by walking the offsets down from `rec`, a record at or after the one
 // holding the chunk's last byte.  Slow, and only used where the fast forms do not apply.
 template <bool COMP, bool FASTQ>
-__device__ __noinline__ void reverse_chunk_generic(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
-                                                   const uint8_t* __restrict__ qin, uint8_t* __restrict__ qout,
-                                                   const uint64_t* __restrict__ offs, uint64_t rec,
-                                                   uint64_t total, uint64_t o, const uint8_t* s_lut)
+__device__ __forceinline__ void reverse_chunk_bytes(const uint8_t* __restrict__ in, const uint8_t* __restrict__ qin,
+                                                    const uint64_t* __restrict__ offs, uint64_t rec, uint64_t total,
+                                                    uint64_t o, const uint8_t* s_lut, uint4& v16, uint4& vq16)
 {
     uint32_t w[4] = {0, 0, 0, 0}, wq[4] = {0, 0, 0, 0};
     uint64_t r = rec;
@@ -214,17 +216,42 @@ __device__ __noinline__ void reverse_chunk_generic(const uint8_t* __restrict__ i
         const uint64_t src = offs[r] + offs[r + 1] - 1 - p;
         uint32_t b = in[src];
         if (COMP) b = s_lut[b];
-        const uint32_t sh = 8 * (k & 3);
-        if (k < 4) w[0] |= b << sh; else if (k < 8) w[1] |= b << sh;
-        else if (k < 12) w[2] |= b << sh; else w[3] |= b << sh;
+        // branch-free: the loaded byte is consumed on every path, so no load is ever left
+        // pending (as the compiler sees it) when this function is left
+        const uint32_t sh = 8 * (k & 3), m = (uint32_t)k >> 2;
+        const uint32_t v = b << sh;
+        w[0] |= m == 0 ? v : 0u; w[1] |= m == 1 ? v : 0u; w[2] |= m == 2 ? v : 0u; w[3] |= m == 3 ? v : 0u;
         if (FASTQ) {
-            const uint32_t bq = qin[src];
-            if (k < 4) wq[0] |= bq << sh; else if (k < 8) wq[1] |= bq << sh;
-            else if (k < 12) wq[2] |= bq << sh; else wq[3] |= bq << sh;
+            const uint32_t vq = (uint32_t)qin[src] << sh;
+            wq[0] |= m == 0 ? vq : 0u; wq[1] |= m == 1 ? vq : 0u; wq[2] |= m == 2 ? vq : 0u; wq[3] |= m == 3 ? vq : 0u;
         }
     }
-    store_clipped(out, 0, total, o, make_uint4(w[0], w[1], w[2], w[3]));
-    if (FASTQ) store_clipped(qout, 0, total, o, make_uint4(wq[0], wq[1], wq[2], wq[3]));
+    v16 = make_uint4(w[0], w[1], w[2], w[3]);
+    vq16 = make_uint4(wq[0], wq[1], wq[2], wq[3]);
+}
+
+template <bool COMP, bool FASTQ>
+__device__ __forceinline__ void reverse_chunk_bytewise(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                       const uint8_t* __restrict__ qin, uint8_t* __restrict__ qout,
+                                                       const uint64_t* __restrict__ offs, uint64_t rec,
+                                                       uint64_t total, uint64_t o, const uint8_t* s_lut)
+{
+    uint4 v, vq;
+    reverse_chunk_bytes<COMP, FASTQ>(in, qin, offs, rec, total, o, s_lut, v, vq);
+    store_clipped(out, 0, total, o, v);
+    if (FASTQ) store_clipped(qout, 0, total, o, vq);
+}
+
+// The same as a real call: for kernels that reach it from several places, so that its code
+// and registers are paid for once (a call parks the caller's live values in the sparse
+// callee-saved registers, so kernels with one call site inline the body instead).
+template <bool COMP, bool FASTQ>
+__device__ __noinline__ void reverse_chunk_generic(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                   const uint8_t* __restrict__ qin, uint8_t* __restrict__ qout,
+                                                   const uint64_t* __restrict__ offs, uint64_t rec,
+                                                   uint64_t total, uint64_t o, const uint8_t* s_lut)
+{
+    reverse_chunk_bytewise<COMP, FASTQ>(in, out, qin, qout, offs, rec, total, o, s_lut);
 }
 
 struct RevPlanes {
@@ -397,6 +424,270 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_reverse_short(RevPlanes P, uint64
         rec0 = next0;
         wo = nwo;
     }
+}
+
+// ---- short records, staged form -------------------------------------------------------------
+//
+// The GW consecutive records a wavefront serves in one step are one contiguous stretch of the
+// plane.  That stretch (plus the tail of the record before it, whose first bytes end up in the
+// first chunk of the step) and the step's slice of the offsets array are copied into LDS by
+// direct global->LDS loads: whole-wavefront, aligned, 1 KiB per instruction -- the fewest
+// memory instructions this work can be done with, which is what the texture addresser charges
+// for.  Every window (including the previous-record window of a head chunk) and every offset is
+// then read from LDS; no lane touches global memory again until its store.
+//
+// Each wavefront cycles through ST_NB private stage buffers: while one step is reversed, looked
+// up and stored, the loads of the next ST_NB-1 steps are in flight.  The loads are issued from
+// inline assembly and awaited by hand: memory operations of a wavefront complete in issue
+// order, every step issues exactly ST_LOADS loads (a step past the end of the batch re-reads
+// the wavefront's first step), so "at most (ST_NB-1)*ST_LOADS operations outstanding" means
+// the current step's data has landed; stores issued in between only make that wait stricter.
+// (Left to the compiler, every LDS read that follows a global->LDS load is preceded by a wait
+// for ALL outstanding memory operations, which serialises the pipeline.)
+constexpr int ST_NB = 3;                            // stage buffers per wavefront
+constexpr uint32_t ST_ROWS = 3;                     // 1-KiB load rows per stage
+constexpr uint32_t ST_BYTES = ST_ROWS * 1024;       // bytes staged per wavefront step
+constexpr uint32_t ST_PAD = 32;                     // a window's second chunk may be read past the stretch
+constexpr uint32_t ST_OFFS = 72;                    // offsets per step: GW + 2 <= 66, loaded as 16-byte pairs
+constexpr int ST_WAVES = SKH_BLOCK / 64;
+constexpr int ST_LOADS = ST_ROWS + 1;               // load instructions per step
+
+struct StageLds {
+    RevLds tab;
+    __attribute__((aligned(16))) uint8_t bytes[ST_WAVES][ST_NB][ST_BYTES + ST_PAD];
+    __attribute__((aligned(16))) uint64_t offs[ST_WAVES][ST_NB][ST_OFFS];
+};
+
+// 16 bytes per lane from global memory straight into LDS at lds_addr + 16 * lane (lds_addr is
+// wave-uniform).  Not visible to the compiler's wait-count bookkeeping: pair with wait_vmcnt.
+__device__ __forceinline__ void load_to_lds16(const void* g, uint32_t lds_addr)
+{
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_addr) : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt()
+{
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+__device__ __forceinline__ uint32_t lds_addr_of(const void* p)
+{
+    return (uint32_t)(uintptr_t)((const __attribute__((address_space(3))) uint8_t*)p);
+}
+
+// plane range [a0, a0 + n) a step must have in LDS, from the offsets just outside its records
+__device__ __forceinline__ void stretch_range(uint64_t first, uint64_t last, uint64_t padded, uint64_t& a0,
+                                              uint64_t& n)
+{
+    const uint64_t lo = first & ~15ull;
+    a0 = lo >= 16 ? lo - 16 : 0;
+    uint64_t a1 = ((last + 15) & ~15ull) + 16;
+    if (a1 > padded) a1 = padded;
+    n = a1 - a0;                                     // >= 16 whenever the plane is not empty
+}
+
+// the window starting at LDS offset lq of the slot, byte-reversed
+__device__ __forceinline__ uint4 lds_window_reversed(const uint8_t* slot, uint32_t lq)
+{
+    const uint32_t base = lq & ~15u;
+    const uint4 lo = *reinterpret_cast<const uint4*>(slot + base);
+    const uint4 hi = *reinterpret_cast<const uint4*>(slot + base + 16);
+    return window_reversed(lo, hi, lq & 15u);
+}
+
+template <bool COMP>
+__global__ __launch_bounds__(SKH_BLOCK) void k_reverse_staged(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                              const uint64_t* __restrict__ offs, uint64_t total,
+                                                              uint64_t nrec, Table256 lut, int logG,
+                                                              uint32_t* __restrict__ n_long)
+{
+    __shared__ StageLds S;
+    rev_lds_init<COMP>(S.tab, lut);
+    const uint32_t G = 1u << logG, j = threadIdx.x & (G - 1);
+    const uint32_t lane = threadIdx.x & 63, GW = 64u >> logG, g = lane >> logG;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint64_t padded = (total + 15) & ~15ull;
+    const uint64_t stride = (uint64_t)gridDim.x * ST_WAVES * GW;
+    const uint64_t rec_first = ((uint64_t)xcd_remap(blockIdx.x, gridDim.x) * ST_WAVES + wave) * GW;
+    if (rec_first >= nrec) return;                   // before anything is in flight
+
+    // The offsets never change while the kernel runs: read through the constant address space,
+    // wave-uniform reads of them are scalar loads, which cost the vector memory path nothing
+    // and do not queue up with the loads below.
+    const auto* coffs = (const __attribute__((address_space(4))) uint64_t*)offs;
+
+    // the offsets just outside the records of the step starting at record r0 (scalar loads:
+    // asked for one iteration before they are needed)
+    struct Bounds { uint64_t first, last; };
+    auto bounds_of = [&](uint64_t r0) {
+        r0 = r0 < nrec ? r0 : rec_first;
+        const uint64_t hi = r0 + GW < nrec ? r0 + GW : nrec;
+        Bounds bd;
+#ifdef SKH_EXP_FIXEDLEN
+        bd.first = r0 ? (r0 - 1) * SKH_EXP_FIXEDLEN : 0;
+        bd.last = hi * SKH_EXP_FIXEDLEN;
+#else
+        bd.first = r0 ? coffs[r0 - 1] : 0;
+        bd.last = coffs[hi];
+#endif
+        return bd;
+    };
+    // puts the loads of the step starting at record r0 in flight towards stage buffer b
+    auto issue = [&](uint64_t r0, const Bounds& bd, uint32_t b) {
+        r0 = r0 < nrec ? r0 : rec_first;
+        const uint64_t ob = r0 ? r0 - 1 : 0;         // first offset of the slice
+        const uint64_t hi = r0 + GW < nrec ? r0 + GW : nrec;
+        uint64_t a0, n;
+        stretch_range(bd.first, bd.last, padded, a0, n);
+        const uint32_t nb = n < ST_BYTES ? (uint32_t)n : ST_BYTES;
+        const uint32_t base = lds_addr_of(&S.bytes[wave][b][0]);
+#pragma unroll
+        for (uint32_t row = 0; row < ST_ROWS; row++) {
+            // lanes past the stretch re-read its last chunk: no branch, constant load count
+            uint32_t off = row * 1024 + lane * 16;
+            off = off < nb ? off : nb - 16;
+            load_to_lds16(in + a0 + off, base + row * 1024);
+        }
+        // offsets ob .. hi as 16-byte pairs; a pair that would run past offs[nrec] is moved
+        // back to the last whole pair (the reader knows offs[nrec] = total without it)
+        const uint32_t npairs = (uint32_t)(hi - ob + 2) >> 1;
+        if (lane < npairs) {
+            uint64_t p = ob + 2ull * lane;
+            p = p < nrec ? p : nrec - 1;
+            load_to_lds16(offs + p, lds_addr_of(&S.offs[wave][b][0]));
+        }
+    };
+
+    uint64_t rec0 = rec_first, rec_issue = rec_first;
+    Bounds ahead = bounds_of(rec_issue);
+#pragma unroll
+    for (int i = 0; i < ST_NB - 1; i++) {
+        const Bounds bd = ahead;
+        ahead = bounds_of(rec_issue + stride);
+        issue(rec_issue, bd, (uint32_t)i);
+        rec_issue += stride;
+    }
+    uint32_t b = 0;
+    while (true) {
+        const uint32_t bf = b + ST_NB - 1;
+        const Bounds bd = ahead;
+        ahead = bounds_of(rec_issue + stride);
+        issue(rec_issue, bd, bf >= ST_NB ? bf - ST_NB : bf);
+        rec_issue += stride;
+        wait_vmcnt<(ST_NB - 1) * ST_LOADS>();        // this step's loads have landed
+
+        uint8_t* slot = S.bytes[wave][b];
+        const uint64_t* L = S.offs[wave][b];
+        const uint32_t i0 = rec0 ? 1u : 0u;          // L[i0] = offs[rec0]
+        const uint32_t bi = g + i0;
+        const uint64_t rec = rec0 + g;
+        uint64_t sprev = 0, s = 0, e = 0;
+        if (rec < nrec) {
+            s = L[bi];
+            e = rec + 1 == nrec ? total : L[bi + 1];
+            sprev = rec ? L[bi - 1] : 0;
+        }
+        // the step as issue() saw it: its records end at e_last, its stretch is [a0, a0 + nst)
+        const uint64_t hi = rec0 + GW < nrec ? rec0 + GW : nrec;
+        const uint64_t s_first = L[i0], e_last = hi == nrec ? total : L[i0 + (uint32_t)(hi - rec0)];
+        uint64_t a0, nst;
+        stretch_range(rec0 ? L[0] : 0, e_last, padded, a0, nst);
+
+        const uint64_t len = e - s;
+        const bool is_long = len > SKH_LONG_T;
+        if (is_long && j == 0) atomicAdd(n_long, 1u);
+        const bool work = !is_long && len != 0;
+        const uint64_t o0 = s & ~15ull;
+        const uint32_t n_own = work ? (uint32_t)((e - o0) >> 4) : 0u;   // chunks that end inside the record
+        const uint32_t sp = (uint32_t)(s - o0);
+        // chunks this lane does byte by byte: bit 0 = the head chunk, when the record before it
+        // is too short to supply its first bytes as one window; bit 1 = the chunk straddling
+        // the plane end
+        uint32_t bytewise = 0;
+        if (work && j == 0) {
+            if (n_own != 0 && sp != 0 && !(sprev <= o0 && sprev + sp >= 16 && e + sp <= padded)) bytewise |= 1u;
+            if (e == total && (e & 15) != 0) bytewise |= 2u;
+        }
+        constexpr uint32_t IT = 3;                   // chunks per lane the coalesced form holds
+        if (nst > ST_BYTES) {
+            // stretch larger than the stage (an outlier among short records): every window
+            // straight from global memory with one misaligned load -- slower, few registers
+            const uint64_t q0 = s + e - 16 - o0;
+            for (uint32_t k = j; k < n_own; k += G) {
+                if (k == 0 && (bytewise & 1u)) continue;
+                uint4 r = reverse16(ldu16(in + q0 - 16ull * k));
+                if (k == 0 && sp != 0)
+                    r = select16(S.tab.low[sp], reverse16(ldu16(in + (sprev + s - 16 - o0))), r);
+                if (COMP) r = map16(r, S.tab.lut);
+                *reinterpret_cast<uint4*>(out + o0 + 16ull * k) = r;
+            }
+        } else if (__any(n_own > IT * G)) {
+            // some record of the step has more chunks than its lanes can hold at once: every
+            // lane stores its chunks as it makes them (64-byte runs per record)
+            const uint32_t lq0 = (uint32_t)(s + e - 16 - o0 - a0);      // window of chunk 0 in the slot
+            for (uint32_t k = j; k < n_own; k += G) {
+                if (k == 0 && (bytewise & 1u)) continue;
+                uint4 r = lds_window_reversed(slot, lq0 - 16 * k);
+                if (k == 0 && sp != 0) {
+                    // the previous record supplies bytes [0, sp) of this chunk
+                    const uint32_t lqp = (uint32_t)(sprev + s - 16 - o0 - a0);
+                    r = select16(S.tab.low[sp], lds_window_reversed(slot, lqp), r);
+                }
+                if (COMP) r = map16(r, S.tab.lut);
+                *reinterpret_cast<uint4*>(out + o0 + 16ull * k) = r;
+            }
+        } else {
+            // The usual case.  The chunks the step owns are one contiguous run of the plane,
+            // [s_first & ~15, e_last & ~15).  Every lane makes its chunks in registers, all of
+            // them are put back into the slot at their OUTPUT positions (after the last window
+            // has been read: a wavefront's LDS operations execute in order), and the run leaves
+            // as whole-wavefront rows: the same bytes as lane-group stores, in a third of the
+            // write requests.
+            const uint32_t lq0 = (uint32_t)(s + e - 16 - o0 - a0);
+            uint4 r[IT];
+#pragma unroll
+            for (uint32_t it = 0; it < IT; it++) {
+                const uint32_t k = j + it * G;
+                if (k < n_own && !(k == 0 && (bytewise & 1u))) {
+                    uint4 v = lds_window_reversed(slot, lq0 - 16 * k);
+                    if (k == 0 && sp != 0) {
+                        const uint32_t lqp = (uint32_t)(sprev + s - 16 - o0 - a0);
+                        v = select16(S.tab.low[sp], lds_window_reversed(slot, lqp), v);
+                    }
+                    if (COMP) v = map16(v, S.tab.lut);
+                    r[it] = v;
+                }
+            }
+            if (bytewise & 1u) {
+                uint4 unused;
+                reverse_chunk_bytes<COMP, false>(in, nullptr, offs, rec, total, o0, S.tab.lut, r[0], unused);
+                bytewise &= ~1u;
+            }
+            const uint32_t w0 = (uint32_t)(o0 - a0);
+#pragma unroll
+            for (uint32_t it = 0; it < IT; it++) {
+                const uint32_t k = j + it * G;
+                if (k < n_own) *reinterpret_cast<uint4*>(slot + w0 + 16 * k) = r[it];
+            }
+            const uint32_t c0 = (uint32_t)((s_first & ~15ull) - a0), c1 = (uint32_t)((e_last & ~15ull) - a0);
+#pragma unroll
+            for (uint32_t row = 0; row < ST_ROWS; row++) {
+                const uint32_t c = row * 1024 + lane * 16;
+                if (c >= c0 && c < c1) *reinterpret_cast<uint4*>(out + a0 + c) = *reinterpret_cast<const uint4*>(slot + c);
+            }
+        }
+#pragma unroll 1
+        while (bytewise) {
+            const uint64_t o = (bytewise & 1u) ? o0 : o0 + 16ull * n_own;
+            bytewise &= (bytewise & 1u) ? ~1u : ~2u;
+            reverse_chunk_bytewise<COMP, false>(in, out, nullptr, nullptr, offs, rec, total, o, S.tab.lut);
+        }
+        rec0 += stride;
+        if (rec0 >= nrec) break;
+        b = b + 1 == ST_NB ? 0 : b + 1;
+    }
+    wait_vmcnt<0>();     // nothing may land in LDS after the wavefront has gone
 }
 
 // Long records: one aligned TILE-byte window of the plane per workgroup iteration.
@@ -993,9 +1284,15 @@ static hipError_t launch_reverse_t(const LaunchCfg& cfg, const uint8_t* in, uint
 {
     const RevPlanes P{in, out, qin, qout, offs, total};
     if (cfg.span_u && !FASTQ) return launch_reverse_span_t<COMP>(cfg, P, nrec, lut, st);
-    const uint32_t g1 = grid_for(nrec, SKH_BLOCK >> cfg.logG, resident_cap(k_reverse_short<COMP, FASTQ>, cfg));
-    hipLaunchKernelGGL((k_reverse_short<COMP, FASTQ>), dim3(g1), dim3(SKH_BLOCK), 0, st, P, nrec, lut,
-                       cfg.logG, n_long);
+    if (cfg.staged && !FASTQ) {
+        const uint32_t g1 = grid_for(nrec, SKH_BLOCK >> cfg.logG, resident_cap(k_reverse_staged<COMP>, cfg));
+        hipLaunchKernelGGL((k_reverse_staged<COMP>), dim3(g1), dim3(SKH_BLOCK), 0, st, P.in, P.out, P.offs, P.total,
+                           nrec, lut, cfg.logG, n_long);
+    } else {
+        const uint32_t g1 = grid_for(nrec, SKH_BLOCK >> cfg.logG, resident_cap(k_reverse_short<COMP, FASTQ>, cfg));
+        hipLaunchKernelGGL((k_reverse_short<COMP, FASTQ>), dim3(g1), dim3(SKH_BLOCK), 0, st, P, nrec, lut,
+                           cfg.logG, n_long);
+    }
     const uint32_t g2 = grid_for((total + SKH_TILE - 1) / SKH_TILE, 1, resident_cap(k_reverse_tiles<COMP, FASTQ>, cfg));
     hipLaunchKernelGGL((k_reverse_tiles<COMP, FASTQ>), dim3(g2), dim3(SKH_BLOCK), 0, st, P, nrec, lut,
                        n_long);

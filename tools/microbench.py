@@ -34,7 +34,10 @@ cases = {
 }
 with torch.cuda.stream(st):
     cases["torch copy_ (2B/base)"] = (lambda: (so.copy_(seq), 0)[1], 2 * total)
+    only = os.environ.get("CASES")          # comma-separated substrings of case names
     for name, (fn, nbytes) in cases.items():
+        if only and not any(w in name for w in only.split(",")):
+            continue
         for _ in range(3):
             fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
