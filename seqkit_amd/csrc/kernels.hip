@@ -37,9 +37,6 @@ namespace skh {
 // meet in the same L2.  Speed only; any mapping is correct.
 __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n)
 {
-#ifdef SKH_NO_XCD_REMAP
-    return b;
-#endif
     const uint32_t q = n >> 3, r = n & 7, x = b & 7, k = b >> 3;
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
 }
@@ -444,7 +441,7 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_reverse_short(RevPlanes P, uint64
 // the current step's data has landed; stores issued in between only make that wait stricter.
 // (Left to the compiler, every LDS read that follows a global->LDS load is preceded by a wait
 // for ALL outstanding memory operations, which serialises the pipeline.)
-constexpr int ST_NB = 3;                            // stage buffers per wavefront
+constexpr int ST_NB = 2;                            // stage buffers per wavefront
 constexpr uint32_t ST_ROWS = 3;                     // 1-KiB load rows per stage
 constexpr uint32_t ST_BYTES = ST_ROWS * 1024;       // bytes staged per wavefront step
 constexpr uint32_t ST_PAD = 32;                     // a window's second chunk may be read past the stretch
@@ -460,6 +457,8 @@ struct StageLds {
 
 // 16 bytes per lane from global memory straight into LDS at lds_addr + 16 * lane (lds_addr is
 // wave-uniform).  Not visible to the compiler's wait-count bookkeeping: pair with wait_vmcnt.
+// M0 (the LDS base of such loads) is a reserved register the compiler sets right before each
+// of its own uses, so overwriting it here needs no clobber.
 __device__ __forceinline__ void load_to_lds16(const void* g, uint32_t lds_addr)
 {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_addr) : "memory");
@@ -499,7 +498,7 @@ __device__ __forceinline__ uint4 lds_window_reversed(const uint8_t* slot, uint32
 template <bool COMP>
 __global__ __launch_bounds__(SKH_BLOCK) void k_reverse_staged(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
                                                               const uint64_t* __restrict__ offs, uint64_t total,
-                                                              uint64_t nrec, Table256 lut, int logG,
+                                                              uint64_t nrec, Table256 lut, int logG, uint32_t steps,
                                                               uint32_t* __restrict__ n_long)
 {
     __shared__ StageLds S;
@@ -508,9 +507,16 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_reverse_staged(const uint8_t* __r
     const uint32_t lane = threadIdx.x & 63, GW = 64u >> logG, g = lane >> logG;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint64_t padded = (total + 15) & ~15ull;
-    const uint64_t stride = (uint64_t)gridDim.x * ST_WAVES * GW;
-    const uint64_t rec_first = ((uint64_t)xcd_remap(blockIdx.x, gridDim.x) * ST_WAVES + wave) * GW;
-    if (rec_first >= nrec) return;                   // before anything is in flight
+    // Workgroup b serves the `steps` * ST_WAVES consecutive steps from b * steps * ST_WAVES on,
+    // its wavefronts interleaved step by step.  The grid covers the batch once: workgroups
+    // start in index order, so the chip sweeps the planes front to back in one narrow window,
+    // which the memory system rewards (a grid-stride loop over resident workgroups keeps
+    // thousands of distant streams open and is ~10% slower on the same work).
+    const uint64_t stride = (uint64_t)ST_WAVES * GW;
+    const uint64_t rec_first = ((uint64_t)blockIdx.x * steps * ST_WAVES + wave) * GW;
+    const uint64_t rec_stop = (uint64_t)(blockIdx.x + 1) * steps * ST_WAVES * GW;
+    const uint64_t rec_end = rec_stop < nrec ? rec_stop : nrec;      // first record not served here
+    if (rec_first >= rec_end) return;                // before anything is in flight
 
     // The offsets never change while the kernel runs: read through the constant address space,
     // wave-uniform reads of them are scalar loads, which cost the vector memory path nothing
@@ -521,21 +527,16 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_reverse_staged(const uint8_t* __r
     // asked for one iteration before they are needed)
     struct Bounds { uint64_t first, last; };
     auto bounds_of = [&](uint64_t r0) {
-        r0 = r0 < nrec ? r0 : rec_first;
+        r0 = r0 < rec_end ? r0 : rec_first;
         const uint64_t hi = r0 + GW < nrec ? r0 + GW : nrec;
         Bounds bd;
-#ifdef SKH_EXP_FIXEDLEN
-        bd.first = r0 ? (r0 - 1) * SKH_EXP_FIXEDLEN : 0;
-        bd.last = hi * SKH_EXP_FIXEDLEN;
-#else
         bd.first = r0 ? coffs[r0 - 1] : 0;
         bd.last = coffs[hi];
-#endif
         return bd;
     };
     // puts the loads of the step starting at record r0 in flight towards stage buffer b
     auto issue = [&](uint64_t r0, const Bounds& bd, uint32_t b) {
-        r0 = r0 < nrec ? r0 : rec_first;
+        r0 = r0 < rec_end ? r0 : rec_first;
         const uint64_t ob = r0 ? r0 - 1 : 0;         // first offset of the slice
         const uint64_t hi = r0 + GW < nrec ? r0 + GW : nrec;
         uint64_t a0, n;
@@ -569,13 +570,22 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_reverse_staged(const uint8_t* __r
         rec_issue += stride;
     }
     uint32_t b = 0;
+    uint32_t rows_stored = 0;     // row stores the previous step issued for certain (wave-uniform)
     while (true) {
         const uint32_t bf = b + ST_NB - 1;
         const Bounds bd = ahead;
         ahead = bounds_of(rec_issue + stride);
         issue(rec_issue, bd, bf >= ST_NB ? bf - ST_NB : bf);
         rec_issue += stride;
-        wait_vmcnt<(ST_NB - 1) * ST_LOADS>();        // this step's loads have landed
+        // this step's loads have landed once at most the loads of the ST_NB-1 steps after it
+        // and the row stores of the step before it are outstanding
+        switch (rows_stored) {
+        case 3: wait_vmcnt<(ST_NB - 1) * ST_LOADS + 3>(); break;
+        case 2: wait_vmcnt<(ST_NB - 1) * ST_LOADS + 2>(); break;
+        case 1: wait_vmcnt<(ST_NB - 1) * ST_LOADS + 1>(); break;
+        default: wait_vmcnt<(ST_NB - 1) * ST_LOADS>(); break;
+        }
+        rows_stored = 0;
 
         uint8_t* slot = S.bytes[wave][b];
         const uint64_t* L = S.offs[wave][b];
@@ -670,11 +680,16 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_reverse_staged(const uint8_t* __r
                 const uint32_t k = j + it * G;
                 if (k < n_own) *reinterpret_cast<uint4*>(slot + w0 + 16 * k) = r[it];
             }
-            const uint32_t c0 = (uint32_t)((s_first & ~15ull) - a0), c1 = (uint32_t)((e_last & ~15ull) - a0);
+            const uint32_t c0 = __builtin_amdgcn_readfirstlane((uint32_t)((s_first & ~15ull) - a0)),
+                           c1 = __builtin_amdgcn_readfirstlane((uint32_t)((e_last & ~15ull) - a0));
 #pragma unroll
             for (uint32_t row = 0; row < ST_ROWS; row++) {
-                const uint32_t c = row * 1024 + lane * 16;
-                if (c >= c0 && c < c1) *reinterpret_cast<uint4*>(out + a0 + c) = *reinterpret_cast<const uint4*>(slot + c);
+                if (row * 1024 < c1 && (row + 1) * 1024 > c0) {      // wave-uniform: some lane of the row stores
+                    const uint32_t c = row * 1024 + lane * 16;
+                    if (c >= c0 && c < c1)
+                        *reinterpret_cast<uint4*>(out + a0 + c) = *reinterpret_cast<const uint4*>(slot + c);
+                    rows_stored++;
+                }
             }
         }
 #pragma unroll 1
@@ -684,7 +699,7 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_reverse_staged(const uint8_t* __r
             reverse_chunk_bytewise<COMP, false>(in, out, nullptr, nullptr, offs, rec, total, o, S.tab.lut);
         }
         rec0 += stride;
-        if (rec0 >= nrec) break;
+        if (rec0 >= rec_end) break;
         b = b + 1 == ST_NB ? 0 : b + 1;
     }
     wait_vmcnt<0>();     // nothing may land in LDS after the wavefront has gone
@@ -1285,9 +1300,12 @@ static hipError_t launch_reverse_t(const LaunchCfg& cfg, const uint8_t* in, uint
     const RevPlanes P{in, out, qin, qout, offs, total};
     if (cfg.span_u && !FASTQ) return launch_reverse_span_t<COMP>(cfg, P, nrec, lut, st);
     if (cfg.staged && !FASTQ) {
-        const uint32_t g1 = grid_for(nrec, SKH_BLOCK >> cfg.logG, resident_cap(k_reverse_staged<COMP>, cfg));
-        hipLaunchKernelGGL((k_reverse_staged<COMP>), dim3(g1), dim3(SKH_BLOCK), 0, st, P.in, P.out, P.offs, P.total,
-                           nrec, lut, cfg.logG, n_long);
+        const uint32_t steps = cfg.staged_steps ? cfg.staged_steps : 2;   // steps per wavefront
+        const uint64_t per_block = (uint64_t)steps * (SKH_BLOCK >> cfg.logG);
+        const uint64_t g1 = (nrec + per_block - 1) / per_block;
+        if (g1 > 0x7fffffffull) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((k_reverse_staged<COMP>), dim3((uint32_t)g1), dim3(SKH_BLOCK), 0, st, P.in, P.out, P.offs,
+                           P.total, nrec, lut, cfg.logG, steps, n_long);
     } else {
         const uint32_t g1 = grid_for(nrec, SKH_BLOCK >> cfg.logG, resident_cap(k_reverse_short<COMP, FASTQ>, cfg));
         hipLaunchKernelGGL((k_reverse_short<COMP, FASTQ>), dim3(g1), dim3(SKH_BLOCK), 0, st, P, nrec, lut,

@@ -58,17 +58,26 @@ int main(int argc, char** argv)
         fflush(stdout);
     };
     char name[128];
-    for (int staged : {1, 0}) {
-        for (uint32_t mg : {0u, 768u, 1024u}) {
-            for (int with_lut : {0, 1}) {
-                skh::LaunchCfg cfg{};
-                cfg.logG = 2; cfg.max_grid = mg; cfg.n_cu = (uint32_t)prop.multiProcessorCount;
-                cfg.staged = staged; cfg.fuse_fastq = 0; cfg.span_u = 0;
-                snprintf(name, sizeof name, "staged=%d max_grid=%u lut=%d", staged, mg, with_lut);
-                timeit(name, [&] {
-                    CK(skh::launch_reverse(cfg, in, out, nullptr, nullptr, offs, nrec, total, with_lut ? &lut : nullptr, flag, st));
-                });
-            }
+    for (uint32_t steps : {1u, 2u, 3u, 4u, 6u}) {
+        for (int with_lut : {0, 1}) {
+            skh::LaunchCfg cfg{};
+            cfg.logG = 2; cfg.max_grid = 0; cfg.n_cu = (uint32_t)prop.multiProcessorCount;
+            cfg.staged = 1; cfg.staged_steps = steps; cfg.fuse_fastq = 0; cfg.span_u = 0;
+            snprintf(name, sizeof name, "staged steps/wave=%u lut=%d", steps, with_lut);
+            timeit(name, [&] {
+                CK(skh::launch_reverse(cfg, in, out, nullptr, nullptr, offs, nrec, total, with_lut ? &lut : nullptr, flag, st));
+            });
+        }
+    }
+    for (uint32_t mg : {0u, 768u}) {
+        for (int with_lut : {0, 1}) {
+            skh::LaunchCfg cfg{};
+            cfg.logG = 2; cfg.max_grid = mg; cfg.n_cu = (uint32_t)prop.multiProcessorCount;
+            cfg.staged = 0; cfg.fuse_fastq = 0; cfg.span_u = 0;
+            snprintf(name, sizeof name, "direct max_grid=%u lut=%d", mg, with_lut);
+            timeit(name, [&] {
+                CK(skh::launch_reverse(cfg, in, out, nullptr, nullptr, offs, nrec, total, with_lut ? &lut : nullptr, flag, st));
+            });
         }
     }
     // involution spot check: out -> in2 must equal in

@@ -178,6 +178,49 @@ __global__ __launch_bounds__(256) void k_wave_asm(const uint8_t* __restrict__ in
     wait_vmcnt<0>();     // nothing may land in LDS after the wavefront has gone
 }
 
+// E: as D, but the plane is cut into segments of 4*K steps; a workgroup sweeps one segment at a
+// time (its 4 wavefronts interleaved), segments are taken grid-stride.  With grid = number of
+// segments every workgroup does exactly one segment and the hardware hands them out in order.
+template <int ROWS, int NB>
+__global__ __launch_bounds__(256) void k_wave_seg(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                   uint64_t nsteps, uint32_t S, uint32_t logK)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t stage[4][NB][ROWS * 1024];
+    const uint32_t lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t K = 1u << logK;
+    const uint64_t nseg = (nsteps + 4 * K - 1) / (4 * K);
+    if (blockIdx.x >= nseg) return;
+    const uint64_t nloc = (uint64_t)K * ((nseg - blockIdx.x + gridDim.x - 1) / gridDim.x);   // local steps
+    auto step_of = [&](uint64_t n) {
+        const uint64_t seg = blockIdx.x + (n >> logK) * gridDim.x;
+        return seg * 4 * K + 4 * (n & (K - 1)) + wave;
+    };
+    auto issue = [&](uint64_t n, uint32_t b) {
+        uint64_t t = n < nloc ? step_of(n) : nsteps;
+        t = t < nsteps ? t : nsteps - 1;
+        const uint32_t base = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) uint8_t*)&stage[wave][b][0]);
+#pragma unroll
+        for (int i = 0; i < ROWS; i++) {
+            uint32_t off = i * 1024 + lane * 16;
+            off = off < S ? off : S - 16;
+            dma16_asm(in + t * S + off, base + i * 1024);
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < NB - 1; i++) issue(i, i);
+    uint32_t b = 0;
+    for (uint64_t n = 0; n < nloc; n++) {
+        uint32_t bf = b + NB - 1;
+        bf = bf >= NB ? bf - NB : bf;
+        issue(n + NB - 1, NB == 1 ? 0 : bf);
+        wait_vmcnt<(NB == 1 ? 0 : (NB - 1) * ROWS)>();
+        const uint64_t t = step_of(n);
+        if (t < nsteps) drain<ROWS>(out, t, S, &stage[wave][b][0], lane);
+        b = b + 1 == NB ? 0 : b + 1;
+    }
+    wait_vmcnt<0>();
+}
+
 
 // F/G: stretch bounds come from an offsets array (GW records per step), as in the real kernels:
 // lanes 0..GW+1 load offs[rec0-1+lane], the first and last value give the stretch.  PERSIST:
@@ -345,6 +388,19 @@ int main(int argc, char** argv)
             if (bpc <= 3) {
                 snprintf(name, sizeof name, "wave/lds NB=4 S=%u grid=%d", S, grid);
                 timeit(name, [&] { hipLaunchKernelGGL((k_wave_lds<3, 4>), dim3(grid), dim3(256), 0, 0, in, out, nsteps, S); });
+            }
+        }
+        if (S == 2400) {
+            for (uint32_t logK : {0u, 2u, 4u, 6u}) {
+                const uint64_t nseg = (nsteps + (4ull << logK) - 1) / (4ull << logK);
+                for (int grid : {768, 1024, 1536, (int)nseg}) {
+                    snprintf(name, sizeof name, "seg NB=1 K=%u grid=%d", 1u << logK, grid);
+                    timeit(name, [&] { hipLaunchKernelGGL((k_wave_seg<3, 1>), dim3(grid), dim3(256), 0, 0, in, out, nsteps, S, logK); });
+                    snprintf(name, sizeof name, "seg NB=2 K=%u grid=%d", 1u << logK, grid);
+                    timeit(name, [&] { hipLaunchKernelGGL((k_wave_seg<3, 2>), dim3(grid), dim3(256), 0, 0, in, out, nsteps, S, logK); });
+                    snprintf(name, sizeof name, "seg NB=3 K=%u grid=%d", 1u << logK, grid);
+                    timeit(name, [&] { hipLaunchKernelGGL((k_wave_seg<3, 3>), dim3(grid), dim3(256), 0, 0, in, out, nsteps, S, logK); });
+                }
             }
         }
         for (int bpc : {2, 3, 4}) {
