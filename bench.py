@@ -236,10 +236,10 @@ def main():
                                    "(reverse-complement + quality reversal) then fx2tab -g -B AGCT counts, "
                                    "resident in HBM" % (nrec, L),
                        "records_per_gpu": nrec, "read_len": L, "parallelism": "records sharded, %d rank(s)" % world},
-            "roofline": {"bound": "hbm", "kernel": "skh::k_reverse_short<true, false> (bases: reverse + complement)",
+            "roofline": {"bound": "hbm", "kernel": "skh::k_reverse_staged<true> (bases: reverse + complement)",
                          "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": measured_traffic("skh::k_reverse_short<true, false>")
+                         "traffic": measured_traffic("skh::k_reverse_staged<true>")
                          if (nrec, L) == (10_000_000, 150) else None,
                          "algorithmic_bytes_per_launch": rev_bytes,
                          "avg_launch_ms": round(rev_ms, 4)},

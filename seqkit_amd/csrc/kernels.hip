@@ -1045,7 +1045,7 @@ __device__ __forceinline__ uint32_t field16(const uint32_t* acc16, uint32_t c)
 template <int NW>
 __global__ __launch_bounds__(SKH_BLOCK) void k_count_short(
     const uint8_t* __restrict__ seq, const uint64_t* __restrict__ offs, uint64_t nrec, uint64_t total,
-    Table256 cls, uint32_t nclass, int logG, uint32_t neutral, uint64_t* __restrict__ counts,
+    Table256 cls, uint32_t nclass, int logG, uint32_t steps, uint32_t neutral, uint64_t* __restrict__ counts,
     uint32_t* __restrict__ n_long)
 {
     __shared__ CountLds<NW> L;
@@ -1055,16 +1055,19 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_count_short(
     const uint32_t neutral4 = (neutral & 0xffu) * 0x01010101u;
     const uint32_t G = 1u << logG, j = threadIdx.x & (G - 1);
     const uint32_t lane = threadIdx.x & 63, GW = 64u >> logG, g = lane >> logG;
-    const uint64_t stride = (uint64_t)gridDim.x * (SKH_BLOCK / 64) * GW;
-    // the wavefront's first record; all its lanes run the same number of steps
-    uint64_t rec0 = ((uint64_t)xcd_remap(blockIdx.x, gridDim.x) * (SKH_BLOCK / 64) + (threadIdx.x >> 6)) * GW;
-    if (rec0 >= nrec) return;
+    // workgroup b serves `steps` consecutive steps per wavefront, wavefronts interleaved; the
+    // grid covers the batch once, in index order (see k_reverse_staged)
+    const uint64_t stride = (uint64_t)(SKH_BLOCK / 64) * GW;
+    uint64_t rec0 = ((uint64_t)blockIdx.x * steps * (SKH_BLOCK / 64) + (threadIdx.x >> 6)) * GW;
+    const uint64_t rec_stop = (uint64_t)(blockIdx.x + 1) * steps * (SKH_BLOCK / 64) * GW;
+    const uint64_t rec_end = rec_stop < nrec ? rec_stop : nrec;
+    if (rec0 >= rec_end) return;
     WaveOffsets wo;
     wo.load(offs, nrec, total, rec0, GW, lane);
     while (true) {
         const uint64_t next0 = rec0 + stride;
         WaveOffsets nwo;
-        if (next0 < nrec) nwo.load(offs, nrec, total, next0, GW, lane);
+        if (next0 < rec_end) nwo.load(offs, nrec, total, next0, GW, lane);
         const uint64_t rec = rec0 + g;
         const uint64_t s = wo.get(g + 1, GW), e = wo.get(g + 2, GW);
         const uint64_t len = e - s;
@@ -1108,7 +1111,7 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_count_short(
         }
         if (rec < nrec)
             for (uint32_t c = j; c < nclass; c += G) counts[rec * nclass + c] = field16<NW>(acc16, c);
-        if (next0 >= nrec) break;
+        if (next0 >= rec_end) break;
         rec0 = next0;
         wo = nwo;
     }
@@ -1353,18 +1356,20 @@ hipError_t launch_count(const LaunchCfg& cfg, const uint8_t* seq, const uint64_t
                         uint64_t* counts, uint32_t* n_long, hipStream_t st)
 {
     const uint64_t ntile = (total + SKH_TILE - 1) / SKH_TILE;
+    const uint32_t steps = cfg.count_steps ? cfg.count_steps : 4;     // steps per wavefront
+    const uint64_t per_block = (uint64_t)steps * (SKH_BLOCK >> cfg.logG);
+    const uint64_t g1 = (nrec + per_block - 1) / per_block;
+    if (g1 > 0x7fffffffull) return hipErrorInvalidValue;
     if (nclass <= 4) {
-        const uint32_t g1 = grid_for(nrec, SKH_BLOCK >> cfg.logG, resident_cap(k_count_short<1>, cfg));
         const uint32_t g2 = grid_for(ntile, 1, resident_cap(k_count_tiles<1>, cfg));
-        hipLaunchKernelGGL((k_count_short<1>), dim3(g1), dim3(SKH_BLOCK), 0, st, seq, offs, nrec, total, cls,
-                           nclass, cfg.logG, neutral, counts, n_long);
+        hipLaunchKernelGGL((k_count_short<1>), dim3((uint32_t)g1), dim3(SKH_BLOCK), 0, st, seq, offs, nrec, total,
+                           cls, nclass, cfg.logG, steps, neutral, counts, n_long);
         hipLaunchKernelGGL((k_count_tiles<1>), dim3(g2), dim3(SKH_BLOCK), 0, st, seq, offs, nrec, total,
                            cls, nclass, neutral, counts, n_long);
     } else {
-        const uint32_t g1 = grid_for(nrec, SKH_BLOCK >> cfg.logG, resident_cap(k_count_short<2>, cfg));
         const uint32_t g2 = grid_for(ntile, 1, resident_cap(k_count_tiles<2>, cfg));
-        hipLaunchKernelGGL((k_count_short<2>), dim3(g1), dim3(SKH_BLOCK), 0, st, seq, offs, nrec, total, cls,
-                           nclass, cfg.logG, neutral, counts, n_long);
+        hipLaunchKernelGGL((k_count_short<2>), dim3((uint32_t)g1), dim3(SKH_BLOCK), 0, st, seq, offs, nrec, total,
+                           cls, nclass, cfg.logG, steps, neutral, counts, n_long);
         hipLaunchKernelGGL((k_count_tiles<2>), dim3(g2), dim3(SKH_BLOCK), 0, st, seq, offs, nrec, total,
                            cls, nclass, neutral, counts, n_long);
     }
