@@ -56,7 +56,7 @@ struct skh_ctx {
     uint32_t max_grid = 0;
     uint32_t n_cu = 256;
     int force_logG = -1;
-    int span_u = 4;
+    int span_u = -1;         // -1 = chosen per call from the mean record length
     int fuse_fastq = 0;
     int staged = 1;
     uint32_t staged_steps = 0;
@@ -87,7 +87,9 @@ skh::LaunchCfg cfg_for(const skh_ctx* ctx, uint64_t nrec, uint64_t total)
     skh::LaunchCfg c;
     c.max_grid = ctx->max_grid;
     c.n_cu = ctx->n_cu;
-    c.span_u = ctx->span_u;
+    // span kernel (lanes own consecutive output chunks) for read sets dominated by records of
+    // many KiB (nanopore-like); lane-group / staged kernels otherwise.  SKH_SPAN_U overrides.
+    c.span_u = ctx->span_u >= 0 ? ctx->span_u : ((nrec && total / nrec >= 8192) ? 4 : 0);
     c.fuse_fastq = ctx->fuse_fastq;
     c.staged = ctx->staged;
     c.staged_steps = ctx->staged_steps;
@@ -145,7 +147,7 @@ int skh_init(int device, skh_ctx** out)
     c->max_grid = (uint32_t)env_int("SKH_MAX_GRID", 0);
     c->n_cu = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256u;
     c->force_logG = env_int("SKH_LOGG", -1);
-    c->span_u = env_int("SKH_SPAN_U", 0);
+    c->span_u = env_int("SKH_SPAN_U", -1);
     c->fuse_fastq = env_int("SKH_FUSE_FASTQ", 0);
     c->staged = env_int("SKH_STAGED", 1);
     c->staged_steps = (uint32_t)env_int("SKH_STAGED_STEPS", 0);

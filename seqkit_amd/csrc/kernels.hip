@@ -155,14 +155,22 @@ __device__ __forceinline__ uint4 reverse16(uint4 w)
                       __builtin_bswap32(w.x));
 }
 
-typedef unsigned short ushort2_t __attribute__((ext_vector_type(2)));
+// (a << sh) | b in one instruction
+template <int SH>
+__device__ __forceinline__ uint32_t lshl_or(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "n"(SH), "v"(b));
+    return r;
+}
 
 __device__ __forceinline__ uint32_t map4(uint32_t w, const uint8_t* s_lut)
 {
-    // two 16-bit pairs so the bytes are packed with two v_perm and one v_lshl_or
-    const ushort2_t a = {(unsigned short)s_lut[w & 0xffu], (unsigned short)s_lut[(w >> 16) & 0xffu]};
-    const ushort2_t b = {(unsigned short)s_lut[(w >> 8) & 0xffu], (unsigned short)s_lut[w >> 24]};
-    return __builtin_bit_cast(uint32_t, a) | (__builtin_bit_cast(uint32_t, b) << 8);
+    // four byte loads packed with three shift-or operations (spelled out: the compiler
+    // re-associates the plain expression into four)
+    const uint32_t b0 = s_lut[w & 0xffu], b1 = s_lut[(w >> 8) & 0xffu], b2 = s_lut[(w >> 16) & 0xffu],
+                   b3 = s_lut[w >> 24];
+    return lshl_or<16>(lshl_or<8>(b3, b2), lshl_or<8>(b1, b0));
 }
 
 __device__ __forceinline__ uint4 map16(uint4 v, const uint8_t* s_lut)
@@ -486,13 +494,16 @@ __device__ __forceinline__ void stretch_range(uint64_t first, uint64_t last, uin
     n = a1 - a0;                                     // >= 16 whenever the plane is not empty
 }
 
-// the window starting at LDS offset lq of the slot, byte-reversed
+// The window starting at LDS offset lq of the slot, byte-reversed.  LDS reads need only dword
+// alignment: the five dwords that hold the window are read as they lie (no dword selection
+// network as for the 16-byte aligned global loads), and four v_perm_b32 shift and reverse.
 __device__ __forceinline__ uint4 lds_window_reversed(const uint8_t* slot, uint32_t lq)
 {
-    const uint32_t base = lq & ~15u;
-    const uint4 lo = *reinterpret_cast<const uint4*>(slot + base);
-    const uint4 hi = *reinterpret_cast<const uint4*>(slot + base + 16);
-    return window_reversed(lo, hi, lq & 15u);
+    const uint32_t* d = reinterpret_cast<const uint32_t*>(slot + (lq & ~3u));
+    const uint32_t V0 = d[0], V1 = d[1], V2 = d[2], V3 = d[3], V4 = d[4];
+    const uint32_t sel = 0x00010203u + (lq & 3u) * 0x01010101u;
+    return make_uint4(__builtin_amdgcn_perm(V4, V3, sel), __builtin_amdgcn_perm(V3, V2, sel),
+                      __builtin_amdgcn_perm(V2, V1, sel), __builtin_amdgcn_perm(V1, V0, sel));
 }
 
 template <bool COMP>

@@ -89,5 +89,19 @@ if "ont" in which:
     rng = np.random.default_rng(0xC4)
     lens = np.clip(np.exp(rng.normal(np.log(8000), 1.1, 700_000)), 1000, 1_000_000).astype(np.int64)
     ok &= run("config4: ONT-like log-normal lengths", lens, 0xC4)
+if "trim" in which:      # adapter-trimmed Illumina reads
+    rng = np.random.default_rng(7)
+    ok &= run("trimmed reads: uniform 30..151", rng.integers(30, 152, 8_000_000), 7)
+if "r100" in which:
+    ok &= run("fixed 100 bp", np.full(10_000_000, 100), 8)
+if "r250" in which:
+    ok &= run("fixed 250 bp", np.full(5_000_000, 250), 9)
+if "mirna" in which:     # hairpin.fa-like: 39..2354, mostly ~100
+    rng = np.random.default_rng(10)
+    ok &= run("hairpin-like log-normal around 100", np.clip(np.exp(rng.normal(np.log(100), 0.35, 8_000_000)), 39, 2354).astype(np.int64), 10)
+if "mixed" in which:     # short reads with a few long contigs in between
+    rng = np.random.default_rng(11)
+    lens = np.full(4_000_000, 150); lens[rng.integers(0, len(lens), 200)] = rng.integers(100_000, 3_000_000, 200)
+    ok &= run("150 bp reads + 200 long contigs", lens, 11)
 lib.skh_destroy(ctx)
 sys.exit(0 if ok else 1)
