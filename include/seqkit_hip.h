@@ -117,6 +117,48 @@ int skh_stats_dev(skh_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_offsets,
                   uint64_t nrec, uint64_t total_bytes, const uint8_t is_gap[256],
                   skh_stats_partial *d_out, void *stream);
 
+/* ---- FASTA/FASTQ text -> batch on the device ----------------------------------------
+ * The step before the hot path: replaces the serial record scanner behind
+ * fastx.NewReader / reader.Read() (call sites seqkit/cmd/seq.go:115-127,
+ * fx2tab.go:96-106, stat.go:87-104) for a block of file text that already lies in
+ * device memory.  Rules: FASTA records start at lines beginning with '>' and run to the
+ * next such line, line ends (LF or CRLF) and blank lines are dropped from the sequence;
+ * FASTQ records are four lines ('@'name, sequence, '+'..., quality of equal length),
+ * blank lines only after the last record (multi-line FASTQ is reported as a format
+ * error).  The name of record r is text[name_pos[r] .. name_pos[r]+name_len[r]).
+ *
+ * `final` != 0 says the text ends at the end of the file; otherwise the last record of
+ * the block is taken to be incomplete and is left for the next call: result.consumed is
+ * where it starts.  The outcome is written to DEVICE memory d_result (read it after
+ * synchronising the stream): status SKH_PARSE_OK, SKH_PARSE_EFORMAT (error_line = first
+ * offending 0-based line of the block) or SKH_PARSE_ECAPACITY (more lines than
+ * max_lines, more records than max_records, or more sequence than seq_capacity: retry
+ * with larger buffers; no output is valid).
+ * d_text must be 16-byte aligned and readable up to skh_padded_size(text_bytes);
+ * d_seq / d_qual (FASTQ only) hold seq_capacity bytes, d_offsets max_records+1 entries,
+ * d_name_pos / d_name_len max_records entries; d_workspace is 256-byte aligned scratch of
+ * skh_parse_workspace_size(text_bytes, max_lines) bytes. */
+#define SKH_FASTA 1
+#define SKH_FASTQ 2
+#define SKH_PARSE_OK        0
+#define SKH_PARSE_EFORMAT   1
+#define SKH_PARSE_ECAPACITY 2
+typedef struct skh_parse_result {
+    uint64_t nrec;        /* complete records found                         */
+    uint64_t seq_bytes;   /* = offsets[nrec]                                */
+    uint64_t consumed;    /* text bytes those records span                  */
+    uint64_t lines;       /* text lines looked at                           */
+    int64_t  error_line;  /* first offending line, or -1                    */
+    uint32_t status;      /* SKH_PARSE_*                                    */
+    uint32_t reserved;
+} skh_parse_result;
+uint64_t skh_parse_workspace_size(uint64_t text_bytes, uint64_t max_lines);
+int skh_parse_dev(skh_ctx *ctx, const uint8_t *d_text, uint64_t text_bytes, int format, int final,
+                  uint8_t *d_seq, uint8_t *d_qual, uint64_t seq_capacity, uint64_t *d_offsets,
+                  uint64_t *d_name_pos, uint32_t *d_name_len, uint64_t max_records,
+                  void *d_workspace, uint64_t workspace_bytes, uint64_t max_lines,
+                  skh_parse_result *d_result, void *stream);
+
 /* ---- pinned-host batches (what a cgo / C++ reader fills) ---------------------------- */
 
 /* Allocates pinned host staging plus matching device buffers for up to max_bytes of

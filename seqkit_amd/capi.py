@@ -20,6 +20,14 @@ class StatsPartial(C.Structure):
         return (self.num, self.len_sum, self.gap_sum, self.len_min, self.len_max)
 
 
+class ParseResult(C.Structure):
+    _fields_ = [("nrec", C.c_uint64), ("seq_bytes", C.c_uint64), ("consumed", C.c_uint64), ("lines", C.c_uint64),
+                ("error_line", C.c_int64), ("status", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+FASTA, FASTQ = 1, 2
+PARSE_OK, PARSE_EFORMAT, PARSE_ECAPACITY = 0, 1, 2
+
 SYMBOLS = {
     "skh_last_error": (C.c_char_p, []),
     "skh_version": (C.c_char_p, []),
@@ -33,6 +41,9 @@ SYMBOLS = {
     "skh_revcomp_fastq_dev": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_uint64, C.c_uint64, u8p, C.c_int, vp]),
     "skh_count_dev": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_uint64, u8p, C.c_uint32, vp, vp]),
     "skh_stats_dev": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_uint64, u8p, vp, vp]),
+    "skh_parse_workspace_size": (C.c_uint64, [C.c_uint64, C.c_uint64]),
+    "skh_parse_dev": (C.c_int, [vp, vp, C.c_uint64, C.c_int, C.c_int, vp, vp, C.c_uint64, vp, vp, vp, C.c_uint64,
+                                vp, C.c_uint64, C.c_uint64, vp, vp]),
     "skh_batch_alloc": (C.c_int, [vp, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(vp)]),
     "skh_batch_free": (None, [vp]),
     "skh_batch_seq": (vp, [vp]),

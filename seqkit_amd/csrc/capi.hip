@@ -319,6 +319,37 @@ int skh_stats_dev(skh_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_offsets,
     return SKH_OK;
 }
 
+// ---------------------------------------------------------------- text -> batch
+
+uint64_t skh_parse_workspace_size(uint64_t text_bytes, uint64_t max_lines)
+{
+    return skh::parse_workspace_size(text_bytes, max_lines ? max_lines : 1);
+}
+
+int skh_parse_dev(skh_ctx* ctx, const uint8_t* d_text, uint64_t text_bytes, int format, int final,
+                  uint8_t* d_seq, uint8_t* d_qual, uint64_t seq_capacity, uint64_t* d_offsets,
+                  uint64_t* d_name_pos, uint32_t* d_name_len, uint64_t max_records, void* d_workspace,
+                  uint64_t workspace_bytes, uint64_t max_lines, skh_parse_result* d_result, void* stream)
+{
+    static_assert(sizeof(skh_parse_result) == sizeof(skh::ParseResult), "layout");
+    if (!ctx) return fail(SKH_EINVAL, "ctx is NULL");
+    if (format != SKH_FASTA && format != SKH_FASTQ) return fail(SKH_EINVAL, "format must be SKH_FASTA or SKH_FASTQ");
+    if (!d_offsets || !d_name_pos || !d_name_len || !d_workspace || !d_result) return fail(SKH_EINVAL, "NULL argument");
+    if (text_bytes != 0 && (!d_text || !d_seq)) return fail(SKH_EINVAL, "NULL text or sequence buffer");
+    if (format == SKH_FASTQ && text_bytes != 0 && !d_qual) return fail(SKH_EINVAL, "FASTQ needs a quality buffer");
+    if (reinterpret_cast<uintptr_t>(d_text) & 15) return fail(SKH_EINVAL, "text buffer is not 16-byte aligned");
+    if (reinterpret_cast<uintptr_t>(d_workspace) & 255) return fail(SKH_EINVAL, "workspace is not 256-byte aligned");
+    if (max_lines == 0) return fail(SKH_EINVAL, "max_lines is 0");
+    if (workspace_bytes < skh::parse_workspace_size(text_bytes, max_lines))
+        return fail(SKH_ECAPACITY, "workspace smaller than skh_parse_workspace_size(text_bytes, max_lines)");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    HIP_TRY(skh::launch_parse(format == SKH_FASTQ, d_text, text_bytes, final != 0, d_seq, d_qual, seq_capacity,
+                              d_offsets, d_name_pos, d_name_len, max_records, d_workspace, max_lines,
+                              reinterpret_cast<skh::ParseResult*>(d_result), st));
+    return SKH_OK;
+}
+
 // ---------------------------------------------------------------- pinned batches
 
 int skh_batch_alloc(skh_ctx* ctx, uint64_t max_bytes, uint64_t max_records, int with_qual, skh_batch** out)

@@ -37,4 +37,23 @@ hipError_t launch_count(const LaunchCfg& cfg, const uint8_t* seq, const uint64_t
 hipError_t launch_stats(const LaunchCfg& cfg, const uint8_t* seq, const uint64_t* offs, uint64_t nrec,
                         uint64_t total, const Table256& is_gap, StatsPartial* out, hipStream_t st);
 
+// ---- text -> batch (parse.hip) ----------------------------------------------------------
+
+enum : uint32_t { PARSE_OK = 0, PARSE_EFORMAT = 1, PARSE_ECAPACITY = 2 };
+
+struct ParseResult {          // mirrors skh_parse_result of the C ABI
+    uint64_t nrec;            // complete records found
+    uint64_t seq_bytes;       // = offsets[nrec]
+    uint64_t consumed;        // text bytes those records span; the next block starts there
+    uint64_t lines;           // text lines looked at
+    int64_t error_line;       // 0-based line of the first format violation, or -1
+    uint32_t status;          // PARSE_*
+    uint32_t pad;
+};
+
+uint64_t parse_workspace_size(uint64_t text_bytes, uint64_t max_lines);
+hipError_t launch_parse(int fastq, const uint8_t* text, uint64_t n, int final, uint8_t* seq, uint8_t* qual,
+                        uint64_t seq_capacity, uint64_t* offsets, uint64_t* name_pos, uint32_t* name_len,
+                        uint64_t max_records, void* workspace, uint64_t max_lines, ParseResult* res, hipStream_t s);
+
 }  // namespace skh

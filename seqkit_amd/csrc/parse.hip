@@ -1,0 +1,551 @@
+// parse.hip -- FASTA / FASTQ text -> CSR batch on the GPU (gfx950).
+//
+// The step BEFORE the per-record hot path: the reference's commands obtain records from
+// fastx.Reader (call sites seqkit/cmd/seq.go:115-127, fx2tab.go:96-106, stat.go:87-104), a
+// serial byte scanner.  Here a block of file text that already lies in HBM is turned into the
+// batch layout of the other kernels -- sequence plane, quality plane, offsets, name spans --
+// by data-parallel passes, all of them streaming and HBM-bound:
+//
+//   1. newline index   count '\n' per 4-KiB tile, scan the tile counts, scatter positions
+//   2. line table      per line: start, length without trailing '\r', head flag, and the
+//                      bytes it contributes to the sequence plane
+//   3. scan            exclusive sums over lines of (contribution, head flag): a line's place
+//                      in the plane and the record it belongs to
+//   4. emit            offsets[] and name spans at head lines; copy of every sequence (and
+//                      quality) line to its place
+//
+// Rules (the same the host reader of this repository applies, fastx_reader.cpp):
+//   FASTA  a record starts at a line whose first byte is '>', and runs to the next such line;
+//          line ends ("\n", "\r\n") and blank lines are dropped from the sequence, nothing else
+//          is; the name is the head line without '>'.
+//   FASTQ  four lines per record: '@'name, sequence, '+'..., quality of the same length.
+//          Blank lines are accepted only after the last record.  (Multi-line FASTQ cannot be
+//          told apart from data without a serial scan -- '@' may start a quality line -- and is
+//          reported as a format error by this parser.)
+// A block that is not the last of its file ends in an incomplete record: `consumed` tells the
+// caller where that record starts, so that the next block can begin there.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.h"
+
+namespace skh {
+
+namespace {
+
+constexpr int PB = 256;                      // threads per workgroup
+constexpr uint32_t TILE = PB * 16;           // text bytes per workgroup in the newline passes
+constexpr int SCAN_ITEMS = 8;                // items per thread in the line scans
+constexpr uint32_t SCAN_TILE = PB * SCAN_ITEMS;
+
+struct LineSum { uint64_t bytes; uint32_t heads; };
+
+__device__ __forceinline__ uint32_t nl_mask16(uint4 v)       // bit k set: byte k is '\n'
+{
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint32_t m = 0;
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        const uint32_t x = w[d] ^ 0x0a0a0a0au;              // zero byte where '\n'
+        // exact zero-byte detector: 0x80 in every byte of x that is zero, nothing elsewhere
+        const uint32_t z = ~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x | 0x7f7f7f7fu);
+        m |= (((z >> 7) & 1u) | ((z >> 14) & 2u) | ((z >> 21) & 4u) | ((z >> 28) & 8u)) << (4 * d);
+    }
+    return m;
+}
+
+// block-wide exclusive scan of one uint32 per thread; returns the exclusive prefix, *total = sum
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* total, uint32_t* s_wave)
+{
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(inc, d);
+        if ((int)lane >= d) inc += t;
+    }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0, sum = 0;
+#pragma unroll
+    for (int w = 0; w < PB / 64; w++) {
+        if (w < (int)wave) base += s_wave[w];
+        sum += s_wave[w];
+    }
+    __syncthreads();
+    *total = sum;
+    return base + inc - v;
+}
+
+// ---- pass 1: newline index ---------------------------------------------------------------
+
+__global__ __launch_bounds__(PB) void k_nl_count(const uint8_t* __restrict__ text, uint64_t n,
+                                                 uint32_t* __restrict__ tile_count)
+{
+    __shared__ uint32_t s_wave[PB / 64];
+    const uint64_t o = (uint64_t)blockIdx.x * TILE + threadIdx.x * 16;
+    uint32_t c = 0;
+    if (o < n) {
+        uint32_t m = nl_mask16(*reinterpret_cast<const uint4*>(text + o));
+        if (o + 16 > n) m &= (1u << (n - o)) - 1u;
+        c = __builtin_popcount(m);
+    }
+    uint32_t total;
+    block_excl_scan(c, &total, s_wave);
+    if (threadIdx.x == 0) tile_count[blockIdx.x] = total;
+}
+
+// exclusive scan of ntile uint32 counts into uint64 bases by ONE workgroup; total -> *n_out
+__global__ __launch_bounds__(1024) void k_scan_tiles(const uint32_t* __restrict__ cnt, uint64_t ntile,
+                                                     uint64_t* __restrict__ base, uint64_t* __restrict__ n_out)
+{
+    __shared__ uint64_t s_part[1024];
+    const uint64_t per = (ntile + 1023) / 1024;
+    const uint64_t a = threadIdx.x * per, b = a + per < ntile ? a + per : ntile;
+    uint64_t s = 0;
+    for (uint64_t i = a; i < b; i++) s += cnt[i];
+    s_part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t run = 0;
+        for (int i = 0; i < 1024; i++) { const uint64_t t = s_part[i]; s_part[i] = run; run += t; }
+        *n_out = run;
+    }
+    __syncthreads();
+    uint64_t run = s_part[threadIdx.x];
+    for (uint64_t i = a; i < b; i++) { base[i] = run; run += cnt[i]; }
+}
+
+__global__ __launch_bounds__(PB) void k_nl_scatter(const uint8_t* __restrict__ text, uint64_t n,
+                                                   const uint64_t* __restrict__ tile_base,
+                                                   uint64_t* __restrict__ nlpos, uint64_t max_lines)
+{
+    __shared__ uint32_t s_wave[PB / 64];
+    const uint64_t o = (uint64_t)blockIdx.x * TILE + threadIdx.x * 16;
+    uint32_t m = 0;
+    if (o < n) {
+        m = nl_mask16(*reinterpret_cast<const uint4*>(text + o));
+        if (o + 16 > n) m &= (1u << (n - o)) - 1u;
+    }
+    uint32_t total;
+    const uint32_t ex = block_excl_scan(__builtin_popcount(m), &total, s_wave);
+    uint64_t k = tile_base[blockIdx.x] + ex;
+    while (m) {
+        const uint32_t bit = __builtin_ctz(m);
+        m &= m - 1;
+        if (k < max_lines) nlpos[k] = o + bit;
+        k++;
+    }
+}
+
+// ---- pass 2: line table ------------------------------------------------------------------
+
+struct ParseState {            // device scratch shared by the passes of one call
+    uint64_t n_nl;             // newlines in the text
+    uint64_t nlines;           // lines considered: newline-terminated ones, + an unterminated last line when final
+    unsigned long long err_line;           // first line that breaks the format (min), ~0 = none
+    unsigned long long last_nonblank;      // last non-blank line (max); valid if any_nonblank
+    unsigned long long first_blank_head;   // FASTQ: first blank line in a head position (min), ~0 = none
+    uint32_t any_nonblank;
+    uint32_t status;
+    LineSum total;             // totals of the line scan
+    uint64_t nrec, seq_bytes, consumed;    // the decision
+};
+
+__global__ void k_parse_init(ParseState* st, uint64_t n, int final, const uint8_t* __restrict__ text,
+                             uint64_t max_lines)
+{
+    uint64_t nl = st->n_nl;
+    uint64_t lines = nl;
+    if (final && n != 0 && text[n - 1] != '\n') lines++;          // unterminated last line
+    if (lines > max_lines) lines = max_lines;                      // reported as capacity error later
+    st->nlines = lines;
+    st->err_line = ~0ull;
+    st->last_nonblank = 0;
+    st->first_blank_head = ~0ull;
+    st->any_nonblank = 0;
+    st->total.bytes = 0;
+    st->total.heads = 0;
+}
+
+__device__ __forceinline__ void line_span(const uint8_t* __restrict__ text, uint64_t n,
+                                          const uint64_t* __restrict__ nlpos, uint64_t n_nl, uint64_t i,
+                                          uint64_t& ls, uint32_t& len)
+{
+    ls = i ? nlpos[i - 1] + 1 : 0;
+    uint64_t le = i < n_nl ? nlpos[i] : n;
+    while (le > ls && text[le - 1] == '\r') le--;
+    len = (uint32_t)(le - ls);            // lines are shorter than 4 GiB (checked by the host side)
+}
+
+template <bool FASTQ>
+__global__ __launch_bounds__(PB) void k_line_table(const uint8_t* __restrict__ text, uint64_t n,
+                                                   const uint64_t* __restrict__ nlpos, ParseState* st,
+                                                   uint64_t* __restrict__ line_start, uint32_t* __restrict__ line_len,
+                                                   uint8_t* __restrict__ line_head)
+{
+    const uint64_t nlines = st->nlines, n_nl = st->n_nl;
+    for (uint64_t i = (uint64_t)blockIdx.x * PB + threadIdx.x; i < nlines; i += (uint64_t)gridDim.x * PB) {
+    uint64_t ls; uint32_t len;
+    line_span(text, n, nlpos, n_nl, i, ls, len);
+    const uint8_t c = len ? text[ls] : 0;
+    bool head, bad = false;
+    if (!FASTQ) {
+        head = c == '>';
+    } else {
+        const uint32_t role = (uint32_t)(i & 3);
+        head = role == 0;
+        if (role == 0) {
+            if (len == 0) atomicMin(&st->first_blank_head, (unsigned long long)i);
+            else bad = c != '@';
+        } else if (role == 2) {
+            bad = c != '+';
+        } else if (role == 3) {
+            uint64_t ls1; uint32_t len1;
+            line_span(text, n, nlpos, n_nl, i - 2, ls1, len1);
+            bad = len1 != len;
+        }
+    }
+    if (len) {
+        atomicMax(&st->last_nonblank, (unsigned long long)i);
+        st->any_nonblank = 1;
+    }
+    if (bad) atomicMin(&st->err_line, (unsigned long long)i);
+    line_start[i] = ls;
+    line_len[i] = len;
+    line_head[i] = head ? 1 : 0;
+    }
+}
+
+// ---- pass 3: exclusive scan over lines of (bytes contributed, head flag) -------------------
+
+template <bool FASTQ>
+__device__ __forceinline__ LineSum line_item(const uint32_t* __restrict__ line_len,
+                                             const uint8_t* __restrict__ line_head, uint64_t i, uint64_t nlines)
+{
+    LineSum v{0, 0};
+    if (i < nlines) {
+        const bool head = line_head[i] != 0;
+        v.heads = head ? 1u : 0u;
+        if (FASTQ) v.bytes = (i & 3) == 1 ? line_len[i] : 0;
+        else v.bytes = head ? 0 : line_len[i];
+    }
+    return v;
+}
+
+template <bool FASTQ>
+__global__ __launch_bounds__(PB) void k_line_partials(const uint32_t* __restrict__ line_len,
+                                                      const uint8_t* __restrict__ line_head, const ParseState* st,
+                                                      LineSum* __restrict__ part)
+{
+    __shared__ uint64_t s_b[PB / 64];
+    __shared__ uint32_t s_h[PB / 64];
+    const uint64_t nlines = st->nlines;
+    const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    uint64_t b = 0; uint32_t h = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) {
+        const LineSum v = line_item<FASTQ>(line_len, line_head, base + k, nlines);
+        b += v.bytes; h += v.heads;
+    }
+    for (int d = 1; d < 64; d <<= 1) { b += __shfl_xor(b, d); h += __shfl_xor(h, d); }
+    if ((threadIdx.x & 63) == 0) { s_b[threadIdx.x >> 6] = b; s_h[threadIdx.x >> 6] = h; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        LineSum t{0, 0};
+        for (int w = 0; w < PB / 64; w++) { t.bytes += s_b[w]; t.heads += s_h[w]; }
+        part[blockIdx.x] = t;
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_scan_partials(LineSum* __restrict__ part, uint64_t npart, ParseState* st)
+{
+    __shared__ uint64_t s_b[1024];
+    __shared__ uint32_t s_h[1024];
+    const uint64_t per = (npart + 1023) / 1024;
+    const uint64_t a = threadIdx.x * per, b = a + per < npart ? a + per : npart;
+    uint64_t sb = 0; uint32_t sh = 0;
+    for (uint64_t i = a; i < b; i++) { sb += part[i].bytes; sh += part[i].heads; }
+    s_b[threadIdx.x] = sb; s_h[threadIdx.x] = sh;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t rb = 0; uint32_t rh = 0;
+        for (int i = 0; i < 1024; i++) {
+            const uint64_t tb = s_b[i]; const uint32_t th = s_h[i];
+            s_b[i] = rb; s_h[i] = rh; rb += tb; rh += th;
+        }
+        st->total.bytes = rb; st->total.heads = rh;
+    }
+    __syncthreads();
+    uint64_t rb = s_b[threadIdx.x]; uint32_t rh = s_h[threadIdx.x];
+    for (uint64_t i = a; i < b; i++) {
+        const LineSum t = part[i];
+        part[i].bytes = rb; part[i].heads = rh;
+        rb += t.bytes; rh += t.heads;
+    }
+}
+
+template <bool FASTQ>
+__global__ __launch_bounds__(PB) void k_line_scan(const uint32_t* __restrict__ line_len,
+                                                  const uint8_t* __restrict__ line_head, const ParseState* st,
+                                                  const LineSum* __restrict__ part, uint64_t* __restrict__ line_dst,
+                                                  uint32_t* __restrict__ line_rank)
+{
+    __shared__ uint64_t s_b[PB / 64];
+    __shared__ uint32_t s_h[PB / 64];
+    const uint64_t nlines = st->nlines;
+    const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    LineSum v[SCAN_ITEMS];
+    uint64_t b = 0; uint32_t h = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) {
+        v[k] = line_item<FASTQ>(line_len, line_head, base + k, nlines);
+        b += v[k].bytes; h += v[k].heads;
+    }
+    // inclusive scan of the per-thread sums across the wavefront, then across wavefronts
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint64_t ib = b; uint32_t ih = h;
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint64_t tb = __shfl_up(ib, d); const uint32_t th = __shfl_up(ih, d);
+        if ((int)lane >= d) { ib += tb; ih += th; }
+    }
+    if (lane == 63) { s_b[wave] = ib; s_h[wave] = ih; }
+    __syncthreads();
+    uint64_t rb = part[blockIdx.x].bytes + ib - b; uint32_t rh = part[blockIdx.x].heads + ih - h;
+    for (uint32_t w = 0; w < wave; w++) { rb += s_b[w]; rh += s_h[w]; }
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) {
+        if (base + k < nlines) { line_dst[base + k] = rb; line_rank[base + k] = rh; }
+        rb += v[k].bytes; rh += v[k].heads;
+    }
+}
+
+// ---- pass 4: decide, emit, copy -----------------------------------------------------------
+
+__device__ __forceinline__ uint64_t start_of_line(uint64_t k, uint64_t nlines, uint64_t n_nl, uint64_t n,
+                                                  const uint64_t* __restrict__ line_start,
+                                                  const uint64_t* __restrict__ nlpos)
+{
+    if (k < nlines) return line_start[k];
+    if (nlines > n_nl) return n;                         // the last line had no newline: nothing follows
+    return nlines ? nlpos[nlines - 1] + 1 : 0;
+}
+
+// One thread: how many complete records the block holds and where the rest starts.
+template <bool FASTQ>
+__global__ void k_parse_decide(ParseState* st, uint64_t n, int final, uint64_t max_lines,
+                               const uint64_t* __restrict__ nlpos, const uint64_t* __restrict__ line_start,
+                               const uint64_t* __restrict__ line_dst, const uint32_t* __restrict__ line_rank)
+{
+    const uint64_t L = st->nlines, n_nl = st->n_nl;
+    uint64_t nrec = 0, seq_bytes = 0, consumed = 0;
+    uint32_t status = PARSE_OK;
+    if (n_nl + 1 > max_lines) {
+        status = PARSE_ECAPACITY;                        // the line tables were too small for this text
+    } else if (!FASTQ) {
+        const uint64_t H = st->total.heads;
+        if (final) {
+            nrec = H; seq_bytes = st->total.bytes; consumed = n;
+        } else if (H > 1) {
+            // the record of the last head line may continue in the next block: stop before it.
+            // line_rank (heads before a line) is non-decreasing; the last head line is the last
+            // line with rank H-1
+            uint64_t lo = 0, hi = L;                      // first line with rank >= H
+            while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (line_rank[mid] >= H) hi = mid; else lo = mid + 1; }
+            const uint64_t last_head = lo - 1;
+            nrec = H - 1; seq_bytes = line_dst[last_head]; consumed = line_start[last_head];
+        }
+    } else {
+        const unsigned long long err = st->err_line, fbh = st->first_blank_head;
+        uint64_t Leff = L;
+        bool bad = false; uint64_t bad_line = 0;
+        if (fbh != ~0ull && fbh < Leff) {
+            Leff = fbh;                                   // records end at the first blank head line ...
+            if (final && st->any_nonblank && st->last_nonblank > fbh) { bad = true; bad_line = fbh; }   // ... only blank lines may follow
+        }
+        nrec = Leff / 4;
+        if (final && (Leff & 3) != 0 && !bad) { bad = true; bad_line = nrec * 4; }    // truncated last record
+        if (err != ~0ull && (err < nrec * 4 || final) && !(bad && bad_line < err)) { bad = true; bad_line = err; }
+        if (bad) { status = PARSE_EFORMAT; st->err_line = bad_line; nrec = 0; }
+        else {
+            st->err_line = ~0ull;
+            seq_bytes = nrec * 4 < L ? line_dst[nrec * 4] : st->total.bytes;
+            consumed = final ? n : start_of_line(nrec * 4, L, n_nl, n, line_start, nlpos);
+        }
+    }
+    st->status = status; st->nrec = nrec; st->seq_bytes = seq_bytes; st->consumed = consumed;
+}
+
+// Per line: head lines write their record's offset and name span.  FASTA: a non-blank line
+// before the first head line is a format error.
+template <bool FASTQ>
+__global__ __launch_bounds__(PB) void k_parse_emit(ParseState* st, uint64_t max_records,
+                                                   const uint64_t* __restrict__ line_start,
+                                                   const uint32_t* __restrict__ line_len,
+                                                   const uint8_t* __restrict__ line_head,
+                                                   const uint64_t* __restrict__ line_dst,
+                                                   const uint32_t* __restrict__ line_rank,
+                                                   uint64_t* __restrict__ offsets, uint64_t* __restrict__ name_pos,
+                                                   uint32_t* __restrict__ name_len)
+{
+    const uint64_t nrec = st->nrec, nlines = st->nlines;
+    if (st->status != PARSE_OK || nrec > max_records) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) offsets[nrec] = st->seq_bytes;
+    for (uint64_t i = (uint64_t)blockIdx.x * PB + threadIdx.x; i < nlines; i += (uint64_t)gridDim.x * PB) {
+        const bool head = line_head[i] != 0;
+        const uint32_t rank = line_rank[i];
+        if (!FASTQ && !head && rank == 0 && line_len[i] != 0) atomicMin(&st->err_line, (unsigned long long)i);
+        if (head && rank < nrec) {
+            offsets[rank] = line_dst[i];
+            name_pos[rank] = line_start[i] + 1;
+            name_len[rank] = line_len[i] - 1;
+        }
+    }
+}
+
+// Copies every sequence (and quality) line of an accepted record to its place in the planes:
+// 8 lanes per line, 16 bytes per lane and pass.
+template <bool FASTQ>
+__global__ __launch_bounds__(PB) void k_parse_copy(const ParseState* st, uint64_t max_records, uint64_t seq_capacity,
+                                                   const uint8_t* __restrict__ text,
+                                                   const uint64_t* __restrict__ line_start,
+                                                   const uint32_t* __restrict__ line_len,
+                                                   const uint8_t* __restrict__ line_head,
+                                                   const uint64_t* __restrict__ line_dst,
+                                                   const uint32_t* __restrict__ line_rank,
+                                                   uint8_t* __restrict__ seq, uint8_t* __restrict__ qual)
+{
+    constexpr uint32_t G = 8;
+    const uint32_t j = threadIdx.x & (G - 1);
+    const uint64_t nrec = st->nrec, nlines = st->nlines;
+    if (st->status != PARSE_OK || nrec > max_records || st->seq_bytes > seq_capacity) return;
+    for (uint64_t i = ((uint64_t)blockIdx.x * PB + threadIdx.x) / G; i < nlines; i += (uint64_t)gridDim.x * (PB / G)) {
+        uint8_t* dst_plane;
+        uint64_t dst;
+        if (FASTQ) {
+            const uint32_t role = (uint32_t)(i & 3);
+            if ((role != 1 && role != 3) || (i >> 2) >= nrec) continue;
+            dst_plane = role == 1 ? seq : qual;
+            dst = line_dst[role == 1 ? i : i - 2];
+        } else {
+            const uint32_t rank = line_rank[i];
+            if (line_head[i] || rank == 0 || rank - 1 >= nrec) continue;
+            dst_plane = seq;
+            dst = line_dst[i];
+        }
+        const uint32_t len = line_len[i];
+        const uint8_t* src = text + line_start[i];
+        uint8_t* out = dst_plane + dst;
+        for (uint32_t p = j * 16; p < len; p += G * 16) {
+            if (p + 16 <= len) {
+                uint4 v;
+                __builtin_memcpy(&v, src + p, 16);
+                __builtin_memcpy(out + p, &v, 16);
+            } else {
+                for (uint32_t k = p; k < len; k++) out[k] = src[k];
+            }
+        }
+    }
+}
+
+__global__ void k_parse_finish(const ParseState* st, uint64_t max_records, uint64_t seq_capacity,
+                               ParseResult* __restrict__ res)
+{
+    ParseResult r;
+    r.nrec = st->nrec; r.seq_bytes = st->seq_bytes; r.consumed = st->consumed; r.lines = st->nlines;
+    r.status = st->status; r.error_line = -1;
+    if (r.status == PARSE_OK && st->err_line != ~0ull) { r.status = PARSE_EFORMAT; }
+    if (r.status == PARSE_EFORMAT) { r.error_line = (int64_t)st->err_line; r.nrec = 0; r.seq_bytes = 0; r.consumed = 0; }
+    if (r.status == PARSE_OK && (r.nrec > max_records || r.seq_bytes > seq_capacity)) r.status = PARSE_ECAPACITY;
+    *res = r;
+}
+
+}  // namespace
+
+// ---- launcher ------------------------------------------------------------------------------
+
+static inline uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
+
+// Workspace layout for `max_lines` lines and `text_bytes` of text (all sections 256-byte aligned).
+struct ParseLayout {
+    uint64_t state, tile_count, tile_base, nlpos, line_start, line_len, line_head, line_dst, line_rank, part, end;
+    ParseLayout(uint64_t text_bytes, uint64_t max_lines)
+    {
+        const uint64_t ntile = (text_bytes + TILE - 1) / TILE + 1;
+        const uint64_t npart = (max_lines + SCAN_TILE - 1) / SCAN_TILE + 1;
+        uint64_t o = 0;
+        state = o; o = align_up(o + sizeof(ParseState), 256);
+        tile_count = o; o = align_up(o + ntile * 4, 256);
+        tile_base = o; o = align_up(o + ntile * 8, 256);
+        nlpos = o; o = align_up(o + max_lines * 8, 256);
+        line_start = o; o = align_up(o + max_lines * 8, 256);
+        line_len = o; o = align_up(o + max_lines * 4, 256);
+        line_head = o; o = align_up(o + max_lines, 256);
+        line_dst = o; o = align_up(o + max_lines * 8, 256);
+        line_rank = o; o = align_up(o + max_lines * 4, 256);
+        part = o; o = align_up(o + npart * sizeof(LineSum), 256);
+        end = o;
+    }
+};
+
+uint64_t parse_workspace_size(uint64_t text_bytes, uint64_t max_lines)
+{
+    return ParseLayout(text_bytes, max_lines).end;
+}
+
+template <bool FASTQ>
+static hipError_t launch_parse_t(const uint8_t* text, uint64_t n, int final, uint8_t* seq, uint8_t* qual,
+                                 uint64_t seq_capacity, uint64_t* offsets, uint64_t* name_pos, uint32_t* name_len,
+                                 uint64_t max_records, uint8_t* ws, uint64_t max_lines, ParseResult* res, hipStream_t s)
+{
+    const ParseLayout lay(n, max_lines);
+    ParseState* st = reinterpret_cast<ParseState*>(ws + lay.state);
+    uint32_t* tile_count = reinterpret_cast<uint32_t*>(ws + lay.tile_count);
+    uint64_t* tile_base = reinterpret_cast<uint64_t*>(ws + lay.tile_base);
+    uint64_t* nlpos = reinterpret_cast<uint64_t*>(ws + lay.nlpos);
+    uint64_t* line_start = reinterpret_cast<uint64_t*>(ws + lay.line_start);
+    uint32_t* line_len = reinterpret_cast<uint32_t*>(ws + lay.line_len);
+    uint8_t* line_head = ws + lay.line_head;
+    uint64_t* line_dst = reinterpret_cast<uint64_t*>(ws + lay.line_dst);
+    uint32_t* line_rank = reinterpret_cast<uint32_t*>(ws + lay.line_rank);
+    LineSum* part = reinterpret_cast<LineSum*>(ws + lay.part);
+
+    const uint64_t ntile = (n + TILE - 1) / TILE;
+    const uint32_t gt = (uint32_t)(ntile ? ntile : 1);
+    // the line passes are sized for the most lines the tables can hold (the true count is
+    // only known on the device); surplus threads leave at once
+    const uint64_t lines_cap = max_lines < n + 1 ? max_lines : n + 1;
+    auto capped = [](uint64_t blocks) { return (uint32_t)(blocks < 1 ? 1 : (blocks > 16384 ? 16384 : blocks)); };
+    const uint32_t gl = capped((lines_cap + PB - 1) / PB);            // grid-stride kernels
+    const uint64_t npart = (lines_cap + SCAN_TILE - 1) / SCAN_TILE ? (lines_cap + SCAN_TILE - 1) / SCAN_TILE : 1;
+    const uint32_t gc = capped((lines_cap * 8 + PB - 1) / PB);
+
+    hipLaunchKernelGGL(k_nl_count, dim3(gt), dim3(PB), 0, s, text, n, tile_count);
+    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, tile_count, ntile, tile_base, &st->n_nl);
+    hipLaunchKernelGGL(k_nl_scatter, dim3(gt), dim3(PB), 0, s, text, n, tile_base, nlpos, max_lines);
+    hipLaunchKernelGGL(k_parse_init, dim3(1), dim3(1), 0, s, st, n, final, text, max_lines);
+    hipLaunchKernelGGL((k_line_table<FASTQ>), dim3(gl), dim3(PB), 0, s, text, n, nlpos, st, line_start, line_len, line_head);
+    hipLaunchKernelGGL((k_line_partials<FASTQ>), dim3((uint32_t)npart), dim3(PB), 0, s, line_len, line_head, st, part);
+    hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, s, part, npart, st);
+    hipLaunchKernelGGL((k_line_scan<FASTQ>), dim3((uint32_t)npart), dim3(PB), 0, s, line_len, line_head, st, part, line_dst, line_rank);
+    hipLaunchKernelGGL((k_parse_decide<FASTQ>), dim3(1), dim3(1), 0, s, st, n, final, max_lines, nlpos, line_start, line_dst, line_rank);
+    hipLaunchKernelGGL((k_parse_emit<FASTQ>), dim3(gl), dim3(PB), 0, s, st, max_records, line_start, line_len, line_head,
+                       line_dst, line_rank, offsets, name_pos, name_len);
+    hipLaunchKernelGGL((k_parse_copy<FASTQ>), dim3(gc), dim3(PB), 0, s, st, max_records, seq_capacity, text, line_start,
+                       line_len, line_head, line_dst, line_rank, seq, qual);
+    hipLaunchKernelGGL(k_parse_finish, dim3(1), dim3(1), 0, s, st, max_records, seq_capacity, res);
+    return hipGetLastError();
+}
+
+hipError_t launch_parse(int fastq, const uint8_t* text, uint64_t n, int final, uint8_t* seq, uint8_t* qual,
+                        uint64_t seq_capacity, uint64_t* offsets, uint64_t* name_pos, uint32_t* name_len,
+                        uint64_t max_records, void* workspace, uint64_t max_lines, ParseResult* res, hipStream_t s)
+{
+    uint8_t* ws = static_cast<uint8_t*>(workspace);
+    return fastq ? launch_parse_t<true>(text, n, final, seq, qual, seq_capacity, offsets, name_pos, name_len,
+                                        max_records, ws, max_lines, res, s)
+                 : launch_parse_t<false>(text, n, final, seq, qual, seq_capacity, offsets, name_pos, name_len,
+                                         max_records, ws, max_lines, res, s);
+}
+
+}  // namespace skh
