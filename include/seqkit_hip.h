@@ -159,6 +159,39 @@ int skh_parse_dev(skh_ctx *ctx, const uint8_t *d_text, uint64_t text_bytes, int 
                   void *d_workspace, uint64_t workspace_bytes, uint64_t max_lines,
                   skh_parse_result *d_result, void *stream);
 
+/* ---- batch -> FASTA/FASTQ output text on the device ---------------------------------
+ * The step after the hot path: the bytes `seqkit seq` writes for every record
+ * (seqkit/cmd/seq.go:163-276): head line, sequence wrapped by byteutil.WrapByteSlice
+ * ('\n' after every line_width bytes, none after the last chunk, nothing for
+ * line_width 0 or an empty sequence), and for FASTQ "+" and the quality string.
+ * Per record, in this order and each part only if selected:
+ *     [mark if print_seq] name-or-ID '\n'            (print_name; only_id cuts the name
+ *                                                     at its first white space)
+ *     wrapped(sequence) '\n'                         (print_seq)
+ *     ["+\n" if plus_line] wrapped(quality) '\n'     (print_qual)
+ * Records shorter than min_len or longer than max_len (when >= 0) are skipped.
+ * The caller maps the command's flags (-n -s -q -i, FASTQ forces line_width 0,
+ * seq.go:136-138,163-241) onto these fields.  Names are read from the text the batch was
+ * parsed from.  The result (bytes written, or SKH_PARSE_ECAPACITY when out_capacity is too
+ * small: nothing valid was written) goes to DEVICE memory d_result. */
+typedef struct skh_seq_format {
+    int64_t min_len, max_len;   /* < 0 = no limit (seq.go:165-172) */
+    int32_t line_width;
+    uint8_t print_name, print_seq, print_qual, plus_line, only_id;
+    char    mark;               /* '>' or '@' */
+} skh_seq_format;
+typedef struct skh_format_result {
+    uint64_t out_bytes;
+    uint32_t status;            /* SKH_PARSE_OK or SKH_PARSE_ECAPACITY */
+    uint32_t reserved;
+} skh_format_result;
+uint64_t skh_format_workspace_size(uint64_t nrec);
+int skh_format_seq_dev(skh_ctx *ctx, const uint8_t *d_text, const uint64_t *d_name_pos,
+                       const uint32_t *d_name_len, const uint8_t *d_seq, const uint8_t *d_qual,
+                       const uint64_t *d_offsets, uint64_t nrec, const skh_seq_format *fmt,
+                       uint8_t *d_out, uint64_t out_capacity, void *d_workspace,
+                       uint64_t workspace_bytes, skh_format_result *d_result, void *stream);
+
 /* ---- pinned-host batches (what a cgo / C++ reader fills) ---------------------------- */
 
 /* Allocates pinned host staging plus matching device buffers for up to max_bytes of

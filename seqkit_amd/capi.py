@@ -25,6 +25,16 @@ class ParseResult(C.Structure):
                 ("error_line", C.c_int64), ("status", C.c_uint32), ("reserved", C.c_uint32)]
 
 
+class SeqFormat(C.Structure):
+    _fields_ = [("min_len", C.c_int64), ("max_len", C.c_int64), ("line_width", C.c_int32),
+                ("print_name", C.c_uint8), ("print_seq", C.c_uint8), ("print_qual", C.c_uint8),
+                ("plus_line", C.c_uint8), ("only_id", C.c_uint8), ("mark", C.c_char)]
+
+
+class FormatResult(C.Structure):
+    _fields_ = [("out_bytes", C.c_uint64), ("status", C.c_uint32), ("reserved", C.c_uint32)]
+
+
 FASTA, FASTQ = 1, 2
 PARSE_OK, PARSE_EFORMAT, PARSE_ECAPACITY = 0, 1, 2
 
@@ -44,6 +54,9 @@ SYMBOLS = {
     "skh_parse_workspace_size": (C.c_uint64, [C.c_uint64, C.c_uint64]),
     "skh_parse_dev": (C.c_int, [vp, vp, C.c_uint64, C.c_int, C.c_int, vp, vp, C.c_uint64, vp, vp, vp, C.c_uint64,
                                 vp, C.c_uint64, C.c_uint64, vp, vp]),
+    "skh_format_workspace_size": (C.c_uint64, [C.c_uint64]),
+    "skh_format_seq_dev": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_uint64, C.POINTER(SeqFormat), vp, C.c_uint64,
+                                     vp, C.c_uint64, vp, vp]),
     "skh_batch_alloc": (C.c_int, [vp, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(vp)]),
     "skh_batch_free": (None, [vp]),
     "skh_batch_seq": (vp, [vp]),

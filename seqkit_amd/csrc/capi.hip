@@ -350,6 +350,39 @@ int skh_parse_dev(skh_ctx* ctx, const uint8_t* d_text, uint64_t text_bytes, int 
     return SKH_OK;
 }
 
+// ---------------------------------------------------------------- batch -> output text
+
+uint64_t skh_format_workspace_size(uint64_t nrec) { return skh::format_workspace_size(nrec); }
+
+int skh_format_seq_dev(skh_ctx* ctx, const uint8_t* d_text, const uint64_t* d_name_pos, const uint32_t* d_name_len,
+                       const uint8_t* d_seq, const uint8_t* d_qual, const uint64_t* d_offsets, uint64_t nrec,
+                       const skh_seq_format* fmt, uint8_t* d_out, uint64_t out_capacity, void* d_workspace,
+                       uint64_t workspace_bytes, skh_format_result* d_result, void* stream)
+{
+    static_assert(sizeof(skh_format_result) == sizeof(skh::FormatResult), "layout");
+    if (!ctx) return fail(SKH_EINVAL, "ctx is NULL");
+    if (!fmt || !d_offsets || !d_workspace || !d_result) return fail(SKH_EINVAL, "NULL argument");
+    if (nrec != 0 && !d_out) return fail(SKH_EINVAL, "output buffer is NULL");
+    if (fmt->print_name && nrec != 0 && (!d_text || !d_name_pos || !d_name_len))
+        return fail(SKH_EINVAL, "names requested without name spans");
+    if (fmt->print_seq && nrec != 0 && !d_seq) return fail(SKH_EINVAL, "sequence requested without a sequence plane");
+    if (fmt->print_qual && nrec != 0 && !d_qual) return fail(SKH_EINVAL, "quality requested without a quality plane");
+    if (fmt->line_width < 0) return fail(SKH_EINVAL, "line_width is negative");
+    if (reinterpret_cast<uintptr_t>(d_workspace) & 255) return fail(SKH_EINVAL, "workspace is not 256-byte aligned");
+    if (workspace_bytes < skh::format_workspace_size(nrec))
+        return fail(SKH_ECAPACITY, "workspace smaller than skh_format_workspace_size(nrec)");
+    skh::FormatSeqArgs a;
+    a.text = d_text; a.name_pos = d_name_pos; a.name_len = d_name_len; a.seq = d_seq; a.qual = d_qual;
+    a.offsets = d_offsets; a.nrec = nrec; a.min_len = fmt->min_len; a.max_len = fmt->max_len;
+    a.width = (uint32_t)fmt->line_width;
+    a.print_name = fmt->print_name != 0; a.print_seq = fmt->print_seq != 0; a.print_qual = fmt->print_qual != 0;
+    a.plus_line = fmt->plus_line != 0; a.only_id = fmt->only_id != 0; a.mark = (uint8_t)fmt->mark;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    HIP_TRY(skh::launch_format_seq(a, d_out, out_capacity, d_workspace, reinterpret_cast<skh::FormatResult*>(d_result), st));
+    return SKH_OK;
+}
+
 // ---------------------------------------------------------------- pinned batches
 
 int skh_batch_alloc(skh_ctx* ctx, uint64_t max_bytes, uint64_t max_records, int with_qual, skh_batch** out)

@@ -56,4 +56,27 @@ hipError_t launch_parse(int fastq, const uint8_t* text, uint64_t n, int final, u
                         uint64_t seq_capacity, uint64_t* offsets, uint64_t* name_pos, uint32_t* name_len,
                         uint64_t max_records, void* workspace, uint64_t max_lines, ParseResult* res, hipStream_t s);
 
+// ---- batch -> output text (format.hip) ---------------------------------------------------
+
+enum : uint32_t { FORMAT_OK = 0, FORMAT_ECAPACITY = 2 };
+
+struct FormatSeqArgs {
+    const uint8_t* text;          // names are text[name_pos[r] .. +name_len[r])
+    const uint64_t* name_pos;
+    const uint32_t* name_len;
+    const uint8_t* seq;
+    const uint8_t* qual;          // only read when print_qual
+    const uint64_t* offsets;
+    uint64_t nrec;
+    int64_t min_len, max_len;     // < 0 = no limit
+    uint32_t width;               // line width of sequence and quality (0 = no wrapping)
+    uint8_t print_name, print_seq, print_qual, plus_line, only_id, mark;
+};
+
+struct FormatResult { uint64_t out_bytes; uint32_t status; uint32_t pad; };
+
+uint64_t format_workspace_size(uint64_t nrec);
+hipError_t launch_format_seq(const FormatSeqArgs& a, uint8_t* out, uint64_t out_capacity, void* workspace,
+                             FormatResult* res, hipStream_t s);
+
 }  // namespace skh
