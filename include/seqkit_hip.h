@@ -192,6 +192,37 @@ int skh_format_seq_dev(skh_ctx *ctx, const uint8_t *d_text, const uint64_t *d_na
                        uint8_t *d_out, uint64_t out_capacity, void *d_workspace,
                        uint64_t workspace_bytes, skh_format_result *d_result, void *stream);
 
+/* ---- text blocks: file text in, file text out ----------------------------------------
+ * The library-owned form of the two entry points above, for callers that hold file text
+ * in host memory (what a cgo shim or the C++ driver uses instead of a record reader):
+ * a block owns pinned staging for the text, the device planes and tables, and a pinned
+ * output buffer.  Per block of a file: fill skh_text_buffer() with up to
+ * skh_text_capacity() bytes (the unconsumed tail of the previous block first), call
+ * skh_text_parse (upload + parse; grows its tables as needed), then any of revcomp /
+ * stats / format.  All calls are synchronous. */
+typedef struct skh_text skh_text;
+int  skh_text_alloc(skh_ctx *ctx, uint64_t block_bytes, skh_text **out);
+void skh_text_free(skh_text *t);
+uint8_t *skh_text_buffer(skh_text *t);
+uint64_t skh_text_capacity(const skh_text *t);
+/* Uploads text_bytes of the buffer and parses them (skh_parse_dev); *out is host memory.
+ * A format error is reported in out->status, not in the return code. */
+int skh_text_parse(skh_ctx *ctx, skh_text *t, uint64_t text_bytes, int format, int final,
+                   skh_parse_result *out);
+/* Copies offsets[first .. first+count) of the parsed block to host memory. */
+int skh_text_offsets(skh_ctx *ctx, skh_text *t, uint64_t first, uint64_t count, uint64_t *offsets);
+/* Copies sequence bytes [first_byte, first_byte+count) of the block to host memory
+ * (e.g. the head of the first record, for the alphabet guess of seq.go:118-127). */
+int skh_text_sequence(skh_ctx *ctx, skh_text *t, uint64_t first_byte, uint64_t count, uint8_t *dst);
+/* skh_revcomp_dev on the block's planes (qualities reversed too when reverse_qual). */
+int skh_text_revcomp(skh_ctx *ctx, skh_text *t, const uint8_t *lut, int do_reverse, int reverse_qual);
+/* skh_format_seq_dev + download: *out points at out_bytes of pinned memory owned by the
+ * block, valid until its next call. */
+int skh_text_format_seq(skh_ctx *ctx, skh_text *t, const skh_seq_format *fmt,
+                        const uint8_t **out, uint64_t *out_bytes);
+/* skh_stats_dev on the block, merged into *inout. */
+int skh_text_stats(skh_ctx *ctx, skh_text *t, const uint8_t is_gap[256], skh_stats_partial *inout);
+
 /* ---- pinned-host batches (what a cgo / C++ reader fills) ---------------------------- */
 
 /* Allocates pinned host staging plus matching device buffers for up to max_bytes of

@@ -57,6 +57,16 @@ SYMBOLS = {
     "skh_format_workspace_size": (C.c_uint64, [C.c_uint64]),
     "skh_format_seq_dev": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_uint64, C.POINTER(SeqFormat), vp, C.c_uint64,
                                      vp, C.c_uint64, vp, vp]),
+    "skh_text_alloc": (C.c_int, [vp, C.c_uint64, C.POINTER(vp)]),
+    "skh_text_free": (None, [vp]),
+    "skh_text_buffer": (vp, [vp]),
+    "skh_text_capacity": (C.c_uint64, [vp]),
+    "skh_text_parse": (C.c_int, [vp, vp, C.c_uint64, C.c_int, C.c_int, C.POINTER(ParseResult)]),
+    "skh_text_offsets": (C.c_int, [vp, vp, C.c_uint64, C.c_uint64, u64p]),
+    "skh_text_sequence": (C.c_int, [vp, vp, C.c_uint64, C.c_uint64, u8p]),
+    "skh_text_revcomp": (C.c_int, [vp, vp, u8p, C.c_int, C.c_int]),
+    "skh_text_format_seq": (C.c_int, [vp, vp, C.POINTER(SeqFormat), C.POINTER(vp), u64p]),
+    "skh_text_stats": (C.c_int, [vp, vp, u8p, C.POINTER(StatsPartial)]),
     "skh_batch_alloc": (C.c_int, [vp, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(vp)]),
     "skh_batch_free": (None, [vp]),
     "skh_batch_seq": (vp, [vp]),

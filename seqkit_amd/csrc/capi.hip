@@ -584,3 +584,213 @@ int skh_stats_reduce(skh_ctx* ctx, skh_batch* b, uint64_t nrec, const uint8_t is
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------- text blocks (file text in, file text out)
+
+struct skh_text {
+    skh_ctx* ctx = nullptr;
+    hipStream_t stream = nullptr;
+    uint64_t cap = 0;                       // text bytes per block
+    uint64_t max_lines = 0;                 // capacity of the per-line / per-record arrays
+    uint8_t *h_text = nullptr, *d_text = nullptr;
+    uint8_t *d_seq = nullptr, *d_qual = nullptr, *d_seq2 = nullptr, *d_qual2 = nullptr;
+    uint64_t *d_offs = nullptr, *d_npos = nullptr;
+    uint32_t* d_nlen = nullptr;
+    void *d_ws = nullptr, *d_fws = nullptr;
+    uint64_t ws_bytes = 0, fws_bytes = 0;
+    uint8_t *d_out = nullptr, *h_out = nullptr;
+    uint64_t out_cap = 0;
+    void* h_res = nullptr;                  // pinned: results come back here
+    void* d_res = nullptr;
+    // the block parsed last
+    int fastq = 0;
+    uint64_t nrec = 0, seq_bytes = 0, text_bytes = 0;
+    bool transformed = false;               // planes of the block now live in d_seq2 / d_qual2
+};
+
+namespace {
+
+void text_free_lines(skh_text* t)
+{
+    (void)hipFree(t->d_offs); (void)hipFree(t->d_npos); (void)hipFree(t->d_nlen); (void)hipFree(t->d_ws); (void)hipFree(t->d_fws);
+    t->d_offs = t->d_npos = nullptr; t->d_nlen = nullptr; t->d_ws = t->d_fws = nullptr;
+}
+
+hipError_t text_alloc_lines(skh_text* t, uint64_t max_lines)
+{
+    text_free_lines(t);
+    t->max_lines = max_lines;
+    t->ws_bytes = skh::parse_workspace_size(t->cap, max_lines);
+    t->fws_bytes = skh::format_workspace_size(max_lines);
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&t->d_offs), (max_lines + 1) * 8);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&t->d_npos), max_lines * 8);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&t->d_nlen), max_lines * 4);
+    if (e == hipSuccess) e = hipMalloc(&t->d_ws, t->ws_bytes);
+    if (e == hipSuccess) e = hipMalloc(&t->d_fws, t->fws_bytes);
+    return e;
+}
+
+hipError_t text_alloc_out(skh_text* t, uint64_t out_cap)
+{
+    (void)hipFree(t->d_out); (void)hipHostFree(t->h_out);
+    t->d_out = t->h_out = nullptr;
+    t->out_cap = out_cap;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&t->d_out), out_cap);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&t->h_out), out_cap, hipHostMallocDefault);
+    return e;
+}
+
+}  // namespace
+
+int skh_text_alloc(skh_ctx* ctx, uint64_t block_bytes, skh_text** out)
+{
+    if (!ctx || !out) return fail(SKH_EINVAL, "NULL argument");
+    *out = nullptr;
+    HIP_TRY(hipSetDevice(ctx->device));
+    skh_text* t = new (std::nothrow) skh_text;
+    if (!t) return fail(SKH_ENOMEM, "out of host memory");
+    t->ctx = ctx;
+    t->cap = skh_padded_size(block_bytes < 4096 ? 4096 : block_bytes);
+    hipError_t e = hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&t->h_text), t->cap, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&t->d_text), t->cap);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&t->d_seq), t->cap);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&t->d_qual), t->cap);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&t->d_seq2), t->cap);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&t->d_qual2), t->cap);
+    if (e == hipSuccess) e = hipHostMalloc(&t->h_res, 256, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMalloc(&t->d_res, 256);
+    if (e == hipSuccess) e = text_alloc_lines(t, t->cap / 32 + 1024);
+    if (e == hipSuccess) e = text_alloc_out(t, t->cap + t->cap / 8 + 4096);
+    if (e != hipSuccess) {
+        const int rc = hip_fail(e, "allocating a text block");
+        skh_text_free(t);
+        return rc;
+    }
+    *out = t;
+    return SKH_OK;
+}
+
+void skh_text_free(skh_text* t)
+{
+    if (!t) return;
+    (void)hipSetDevice(t->ctx->device);
+    if (t->stream) { (void)hipStreamSynchronize(t->stream); (void)hipStreamDestroy(t->stream); }
+    text_free_lines(t);
+    (void)hipFree(t->d_text); (void)hipFree(t->d_seq); (void)hipFree(t->d_qual); (void)hipFree(t->d_seq2); (void)hipFree(t->d_qual2);
+    (void)hipFree(t->d_out); (void)hipFree(t->d_res);
+    (void)hipHostFree(t->h_text); (void)hipHostFree(t->h_out); (void)hipHostFree(t->h_res);
+    delete t;
+}
+
+uint8_t* skh_text_buffer(skh_text* t) { return t ? t->h_text : nullptr; }
+uint64_t skh_text_capacity(const skh_text* t) { return t ? t->cap : 0; }
+
+int skh_text_parse(skh_ctx* ctx, skh_text* t, uint64_t text_bytes, int format, int final, skh_parse_result* out)
+{
+    if (!ctx || !t || !out) return fail(SKH_EINVAL, "NULL argument");
+    if (text_bytes > t->cap) return fail(SKH_ECAPACITY, "text block larger than its buffer");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpyAsync(t->d_text, t->h_text, skh_padded_size(text_bytes), hipMemcpyHostToDevice, t->stream));
+    for (;;) {
+        int rc = skh_parse_dev(ctx, t->d_text, text_bytes, format, final, t->d_seq, t->d_qual, t->cap, t->d_offs,
+                               t->d_npos, t->d_nlen, t->max_lines, t->d_ws, t->ws_bytes, t->max_lines,
+                               static_cast<skh_parse_result*>(t->d_res), t->stream);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(t->h_res, t->d_res, sizeof(skh_parse_result), hipMemcpyDeviceToHost, t->stream));
+        HIP_TRY(hipStreamSynchronize(t->stream));
+        *out = *static_cast<skh_parse_result*>(t->h_res);
+        if (out->status != SKH_PARSE_ECAPACITY) break;
+        // only the line / record tables can be too small here (the planes hold a whole block)
+        if (t->max_lines > text_bytes + 1) return fail(SKH_EHIP, "parser reports a capacity error with full-size tables");
+        hipError_t e = text_alloc_lines(t, t->max_lines * 4);
+        if (e != hipSuccess) return hip_fail(e, "growing the line tables");
+    }
+    t->fastq = format == SKH_FASTQ;
+    t->nrec = out->status == SKH_PARSE_OK ? out->nrec : 0;
+    t->seq_bytes = out->status == SKH_PARSE_OK ? out->seq_bytes : 0;
+    t->text_bytes = text_bytes;
+    t->transformed = false;
+    return SKH_OK;
+}
+
+int skh_text_offsets(skh_ctx* ctx, skh_text* t, uint64_t first, uint64_t count, uint64_t* offsets)
+{
+    if (!ctx || !t || !offsets) return fail(SKH_EINVAL, "NULL argument");
+    if (first + count > t->nrec + 1) return fail(SKH_EINVAL, "offset range beyond the block's records");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpyAsync(offsets, t->d_offs + first, count * 8, hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    return SKH_OK;
+}
+
+int skh_text_sequence(skh_ctx* ctx, skh_text* t, uint64_t first_byte, uint64_t count, uint8_t* dst)
+{
+    if (!ctx || !t || (!dst && count)) return fail(SKH_EINVAL, "NULL argument");
+    if (first_byte + count > t->seq_bytes) return fail(SKH_EINVAL, "byte range beyond the block's sequence");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpyAsync(dst, (t->transformed ? t->d_seq2 : t->d_seq) + first_byte, count, hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    return SKH_OK;
+}
+
+int skh_text_revcomp(skh_ctx* ctx, skh_text* t, const uint8_t* lut, int do_reverse, int reverse_qual)
+{
+    if (!ctx || !t) return fail(SKH_EINVAL, "NULL argument");
+    if (t->transformed) return fail(SKH_EINVAL, "block was already transformed");
+    if (t->nrec == 0 || (!lut && !do_reverse)) return SKH_OK;
+    int rc = skh_revcomp_dev(ctx, t->d_seq, t->d_seq2, t->d_offs, t->nrec, t->seq_bytes, lut, do_reverse, t->stream);
+    if (rc) return rc;
+    if (t->fastq) {
+        if (do_reverse && reverse_qual)
+            rc = skh_revcomp_dev(ctx, t->d_qual, t->d_qual2, t->d_offs, t->nrec, t->seq_bytes, nullptr, 1, t->stream);
+        else
+            HIP_TRY(hipMemcpyAsync(t->d_qual2, t->d_qual, t->seq_bytes, hipMemcpyDeviceToDevice, t->stream));
+        if (rc) return rc;
+    }
+    t->transformed = true;
+    return SKH_OK;
+}
+
+int skh_text_format_seq(skh_ctx* ctx, skh_text* t, const skh_seq_format* fmt, const uint8_t** out, uint64_t* out_bytes)
+{
+    if (!ctx || !t || !fmt || !out || !out_bytes) return fail(SKH_EINVAL, "NULL argument");
+    *out = nullptr; *out_bytes = 0;
+    if (t->nrec == 0) return SKH_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const uint8_t* seq = t->transformed ? t->d_seq2 : t->d_seq;
+    const uint8_t* qual = t->fastq ? (t->transformed ? t->d_qual2 : t->d_qual) : nullptr;
+    if (fmt->print_qual && !qual) return fail(SKH_EINVAL, "quality requested for a FASTA block");
+    for (;;) {
+        int rc = skh_format_seq_dev(ctx, t->d_text, t->d_npos, t->d_nlen, seq, qual, t->d_offs, t->nrec, fmt, t->d_out,
+                                    t->out_cap, t->d_fws, t->fws_bytes, static_cast<skh_format_result*>(t->d_res),
+                                    t->stream);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(t->h_res, t->d_res, sizeof(skh_format_result), hipMemcpyDeviceToHost, t->stream));
+        HIP_TRY(hipStreamSynchronize(t->stream));
+        const skh_format_result r = *static_cast<skh_format_result*>(t->h_res);
+        if (r.status == SKH_PARSE_OK) {
+            HIP_TRY(hipMemcpyAsync(t->h_out, t->d_out, r.out_bytes, hipMemcpyDeviceToHost, t->stream));
+            HIP_TRY(hipStreamSynchronize(t->stream));
+            *out = t->h_out;
+            *out_bytes = r.out_bytes;
+            return SKH_OK;
+        }
+        hipError_t e = text_alloc_out(t, r.out_bytes + r.out_bytes / 16 + 4096);
+        if (e != hipSuccess) return hip_fail(e, "growing the output buffer");
+    }
+}
+
+int skh_text_stats(skh_ctx* ctx, skh_text* t, const uint8_t is_gap[256], skh_stats_partial* inout)
+{
+    if (!ctx || !t || !is_gap || !inout) return fail(SKH_EINVAL, "NULL argument");
+    if (t->nrec == 0) return SKH_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc = skh_stats_dev(ctx, t->transformed ? t->d_seq2 : t->d_seq, t->d_offs, t->nrec, t->seq_bytes, is_gap,
+                           static_cast<skh_stats_partial*>(t->d_res), t->stream);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(t->h_res, t->d_res, sizeof(skh_stats_partial), hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    skh_stats_merge(inout, static_cast<skh_stats_partial*>(t->h_res));
+    return SKH_OK;
+}

@@ -4,6 +4,8 @@
 // fx2tab.go:95-150, stat.go:86-161) but works a batch at a time: while the GPU transforms or
 // counts batch i, the host formats batch i-1 and parses batch i+1 (two pinned batches,
 // skh_*_submit / skh_batch_wait).
+#include <zlib.h>
+
 #include <algorithm>
 #include <climits>
 #include <cstring>
@@ -24,6 +26,177 @@ struct TwoBatches {
     ~TwoBatches() { for (auto& b : bt) if (b.b) skh_batch_free(b.b); }
 };
 
+// ---- file text in blocks, parsed on the GPU ------------------------------------------------
+//
+// Reads a file (plain or gzip, "-" = stdin) block by block into the pinned buffer of a text
+// block, parses each block on the GPU and hands it to `on_block`; the unconsumed tail of a
+// block (its last, incomplete record) is moved to the front of the next one.  The format is
+// decided by the first non-blank byte; leading blank lines are dropped.
+class TextBlocks {
+public:
+    TextBlocks(skh_ctx* ctx, const std::string& path, uint64_t block_bytes) : ctx_(ctx), path_(path)
+    {
+        fh_ = path == "-" ? gzdopen(0, "rb") : gzopen(path.c_str(), "rb");
+        if (!fh_) { err_ = "open " + path + ": no such file or directory"; return; }
+        gzbuffer((gzFile)fh_, 1 << 20);
+        if (skh_text_alloc(ctx, block_bytes, &t_) != SKH_OK) err_ = skh_last_error();
+    }
+    ~TextBlocks() { if (fh_) gzclose((gzFile)fh_); if (t_) skh_text_free(t_); }
+    bool ok() const { return err_.empty(); }
+    const std::string& error() const { return err_; }
+    bool is_fastq() const { return fastq_; }
+    bool any_record() const { return any_; }
+    skh_text* block() const { return t_; }
+
+    // Parses the next block.  Returns false at the end of the file or on error (see error()).
+    bool next(skh_parse_result& res)
+    {
+        if (!ok() || done_) return false;
+        for (;;) {
+            uint8_t* buf = skh_text_buffer(t_);
+            const uint64_t cap = skh_text_capacity(t_);
+            while (have_ < cap && !eof_) {
+                const uint64_t want = cap - have_ > (1u << 30) ? (1u << 30) : cap - have_;
+                const int n = gzread((gzFile)fh_, buf + have_, (unsigned)want);
+                if (n < 0) { err_ = "read " + path_ + ": input error"; return false; }
+                if (n == 0) eof_ = true;
+                have_ += (uint64_t)n;
+            }
+            if (!format_known_) {
+                uint64_t k = 0;
+                while (k < have_ && (buf[k] == '\n' || buf[k] == '\r')) k++;
+                if (k == have_ && !eof_) { have_ = 0; continue; }          // a block of blank lines
+                if (k) { memmove(buf, buf + k, have_ - k); have_ -= k; }
+                if (have_ == 0) { done_ = true; return false; }            // empty file
+                if (buf[0] == '>') fastq_ = false;
+                else if (buf[0] == '@') fastq_ = true;
+                else { err_ = "error when parsing " + path_ + ": invalid FASTA/Q format"; return false; }
+                format_known_ = true;
+                if (have_ < cap && !eof_) continue;                        // top the block up again
+            }
+            if (skh_text_parse(ctx_, t_, have_, fastq_ ? SKH_FASTQ : SKH_FASTA, eof_, &res) != SKH_OK) {
+                err_ = skh_last_error();
+                return false;
+            }
+            if (res.status == SKH_PARSE_EFORMAT) {
+                err_ = "error when parsing " + path_ + ": invalid FASTA/Q format near line " +
+                       std::to_string(lines_before_ + (uint64_t)res.error_line + 1) +
+                       (fastq_ ? " (multi-line FASTQ needs --host-parse)" : "");
+                return false;
+            }
+            if (res.nrec == 0 && !eof_) {
+                // not one complete record in a full block: double the block and read on
+                skh_text* bigger = nullptr;
+                if (skh_text_alloc(ctx_, cap * 2, &bigger) != SKH_OK) { err_ = skh_last_error(); return false; }
+                memcpy(skh_text_buffer(bigger), buf, have_);
+                skh_text_free(t_);
+                t_ = bigger;
+                continue;
+            }
+            consumed_ = res.consumed;
+            if (eof_) done_ = true;
+            if (res.nrec) any_ = true;
+            return res.nrec != 0 || !done_;
+        }
+    }
+    // Call after the block has been used: keeps its unconsumed tail for the next one.
+    void advance(const skh_parse_result& res)
+    {
+        uint8_t* buf = skh_text_buffer(t_);
+        for (uint64_t k = 0; k < consumed_; k++) lines_before_ += buf[k] == '\n';
+        memmove(buf, buf + consumed_, have_ - consumed_);
+        have_ -= consumed_;
+        consumed_ = 0;
+        (void)res;
+    }
+
+private:
+    skh_ctx* ctx_; std::string path_, err_;
+    void* fh_ = nullptr; skh_text* t_ = nullptr;
+    uint64_t have_ = 0, consumed_ = 0, lines_before_ = 0;
+    bool eof_ = false, done_ = false, format_known_ = false, fastq_ = false, any_ = false;
+};
+
+// alphabet of a file as the reference's reader guesses it: from the first record
+int first_record_alphabet(skh_ctx* ctx, skh_text* t, const GlobalOpts& g, int forced, std::string& err)
+{
+    if (forced >= 0) return forced;
+    uint64_t off[2];
+    if (skh_text_offsets(ctx, t, 0, 2, off) != SKH_OK) { err = skh_last_error(); return -1; }
+    uint64_t n = off[1] - off[0];
+    if (g.guess_len != 0 && n > g.guess_len) n = g.guess_len;
+    std::vector<uint8_t> head(n ? n : 1);
+    if (n && skh_text_sequence(ctx, t, off[0], n, head.data()) != SKH_OK) { err = skh_last_error(); return -1; }
+    return guess_alphabet(head.data(), n, g.guess_len);
+}
+
+// `seq` with parse and output formatting on the GPU (seq.go:114-280 a block at a time)
+int seq_text_path(const GlobalOpts& g, const SeqOpts& o, const std::vector<std::string>& files, skh_ctx* ctx, Sink& out)
+{
+    bool is_fastq = false, check_type = true;        // seq.go:105-106: decided once, by the first printed record
+    std::vector<uint64_t> offs;
+    for (const std::string& file : files) {
+        TextBlocks tb(ctx, file, g.batch_bytes);
+        if (!tb.ok()) return fatal(tb.error());
+        uint8_t lut[256];
+        bool lut_ready = false;
+        skh_parse_result res;
+        while (tb.next(res)) {
+            skh_text* t = tb.block();
+            if (res.nrec == 0) { tb.advance(res); continue; }
+            if (o.complement && !lut_ready) {
+                std::string err;
+                const int ab = first_record_alphabet(ctx, t, g, g.alphabet, err);
+                if (ab < 0) return fatal(err);
+                if (!g.quiet && (ab == Protein || ab == Unlimit))
+                    fprintf(stderr, "[WARN] Complement does no take effect on protein/unlimit sequence\n");
+                skh_pair_table(ab, lut);
+                lut_ready = true;
+            }
+            if (o.reverse || o.complement) {
+                // seq.go:187-195: ReverseInplace (bases and qualities), then ComplementInplace
+                if (skh_text_revcomp(ctx, t, o.complement ? lut : nullptr, o.reverse, 1) != SKH_OK) return fatal(skh_last_error());
+            }
+            if (check_type) {
+                // the first record that passes the length filters decides how everything is printed
+                offs.resize(res.nrec + 1);
+                if (skh_text_offsets(ctx, t, 0, res.nrec + 1, offs.data()) != SKH_OK) return fatal(skh_last_error());
+                for (uint64_t r = 0; r < res.nrec && check_type; r++) {
+                    const uint64_t len = offs[r + 1] - offs[r];
+                    if (o.min_len >= 0 && len < (uint64_t)o.min_len) continue;
+                    if (o.max_len >= 0 && len > (uint64_t)o.max_len) continue;
+                    is_fastq = tb.is_fastq() && len > 0;
+                    check_type = false;
+                }
+            }
+            if (!check_type) {
+                skh_seq_format f;
+                memset(&f, 0, sizeof f);
+                f.min_len = o.min_len; f.max_len = o.max_len;
+                f.line_width = tb.is_fastq() ? 0 : g.line_width;           // seq.go:136-138
+                f.print_name = 1; f.print_seq = 1; f.print_qual = is_fastq; f.plus_line = 1;
+                if (o.only_name && o.only_seq) {}
+                else if (o.only_name) { f.print_seq = 0; f.print_qual = 0; }
+                else if (o.only_seq) { f.print_name = 0; f.print_qual = 0; }
+                else if (o.only_qual) {
+                    if (!is_fastq) return fatal("FASTA format has no quality. So do not just use flag -q (--qual)");
+                    f.print_name = 0; f.print_seq = 0; f.print_qual = 1; f.plus_line = 0;
+                }
+                if (f.print_qual && !tb.is_fastq()) f.print_qual = 0;      // a FASTA file after a FASTQ one
+                f.only_id = o.only_id;
+                f.mark = is_fastq ? '@' : '>';
+                const uint8_t* text = nullptr;
+                uint64_t nbytes = 0;
+                if (skh_text_format_seq(ctx, t, &f, &text, &nbytes) != SKH_OK) return fatal(skh_last_error());
+                out.write(text, nbytes);
+            }
+            tb.advance(res);
+        }
+        if (!tb.error().empty()) return fatal(tb.error());
+    }
+    return 0;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------ seq
@@ -33,6 +206,7 @@ int cmd_seq(const GlobalOpts& g, const SeqOpts& o, const std::vector<std::string
     if (skh_init(g.device, &ctx.c) != SKH_OK) return fatal(skh_last_error());
     Sink out(g.out_file);
     if (!out.ok()) return fatal("open " + g.out_file + ": cannot create");
+    if (!g.host_parse) return seq_text_path(g, o, files, ctx.c, out);
     bool is_fastq = false, check_type = true;        // seq.go:105-106: decided once, by the first record
     TwoBatches tb;
 

@@ -98,6 +98,9 @@ struct GlobalOpts {
     size_t guess_len = 10000;     // --alphabet-guess-seq-length
     int device = 0;               // --device (extension: which GPU)
     uint64_t batch_bytes = 256ull << 20, batch_records = 4ull << 20;
+    bool host_parse = false;      // --host-parse: records are scanned and printed by the host
+                                  // (needed for multi-line FASTQ); default: file text is parsed
+                                  // and, for seq, formatted on the GPU
 };
 struct SeqOpts { bool reverse = false, complement = false, only_name = false, only_seq = false,
                  only_qual = false, only_id = false; int min_len = -1, max_len = -1; };

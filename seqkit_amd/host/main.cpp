@@ -92,7 +92,8 @@ int usage()
             "  seqkit-hip fx2tab [-l] [-g] [-G] [-B bases]... [-n] [-i] [-H] [-a] [global flags] [files...]\n"
             "  seqkit-hip stats  [-a] [-T] [-G gap-letters] [global flags] [files...]\n\n"
             "Global flags: -t/--seq-type dna|rna|protein|unlimit|auto, -j/--threads N, -w/--line-width N,\n"
-            "  -o/--out-file FILE, --quiet, --alphabet-guess-seq-length N, --device N\n");
+            "  -o/--out-file FILE, --quiet, --alphabet-guess-seq-length N, --device N,\n"
+            "  --batch-bytes N (text block / batch size), --host-parse (scan and print records on the host)\n");
     return 255;
 }
 
@@ -109,7 +110,7 @@ int main(int argc, char** argv)
     p.flags = {{"t", "seq-type", true}, {"j", "threads", true}, {"w", "line-width", true}, {"o", "out-file", true},
                {nullptr, "quiet", false}, {nullptr, "alphabet-guess-seq-length", true}, {nullptr, "device", true},
                {nullptr, "id-regexp", true}, {nullptr, "id-ncbi", false},
-               {nullptr, "batch-bytes", true}, {nullptr, "batch-records", true}};
+               {nullptr, "batch-bytes", true}, {nullptr, "batch-records", true}, {nullptr, "host-parse", false}};
     if (is_seq) {
         const Flag f[] = {{"r", "reverse", false}, {"p", "complement", false}, {"n", "name", false}, {"s", "seq", false},
                           {"q", "qual", false}, {"i", "only-id", false}, {"m", "min-len", true}, {"M", "max-len", true}};
@@ -142,6 +143,7 @@ int main(int argc, char** argv)
     g.device = atoi(p.value("device", "0").c_str());
     g.batch_bytes = strtoull(p.value("batch-bytes", "268435456").c_str(), nullptr, 10);
     g.batch_records = strtoull(p.value("batch-records", "4194304").c_str(), nullptr, 10);
+    g.host_parse = p.has("host-parse");
     if (p.has("id-regexp") || p.has("id-ncbi"))
         return fatal("--id-regexp / --id-ncbi are not supported by this driver (default ID rule only)");
     std::vector<std::string> files = p.args;

@@ -1,6 +1,8 @@
-"""End-to-end parity of the `seqkit-hip` driver (reader -> CSR batches -> HIP kernels ->
-formatter): its bytes on stdout must equal the reference's documented outputs and the CPU
-oracle's output for the same command line, on every fixture of the reference's tests."""
+"""End-to-end parity of the `seqkit-hip` driver: its bytes on stdout must equal the reference's
+documented outputs and the CPU oracle's output for the same command line, on every fixture of
+the reference's tests.  Both ways through the driver are covered: the default (file text parsed
+and formatted on the GPU) and --host-parse (host reader -> CSR batches -> kernels -> host
+formatter)."""
 import json
 import os
 
@@ -34,24 +36,49 @@ SEQ_VARIANTS = [["-r", "-p"], ["-r"], ["-p"], [], ["-r", "-p", "-w", "0"], ["-rp
                 ["-r", "-p", "-m", "100", "-M", "160"], ["-r", "-p", "-w", "7"]]
 
 
+MODES = [[], ["--host-parse"]]
+
+
+@pytest.mark.parametrize("mode", MODES, ids=["gpu-text", "host-parse"])
 @pytest.mark.parametrize("f", FILES)
 @pytest.mark.parametrize("flags", SEQ_VARIANTS, ids=lambda v: " ".join(v) or "plain")
-def test_seq_matches_oracle(cli, oracle_cli, f, flags):
+def test_seq_matches_oracle(cli, oracle_cli, f, flags, mode):
     want = run_cli(oracle_cli, ["seq"] + flags + [f])
-    got = run_cli(cli, ["seq"] + flags + [f])
+    got = run_cli(cli, ["seq"] + mode + flags + [f])
     assert got[0] == want[0] == 0 and got[1] == want[1]
 
 
-def test_seq_small_batches_and_qual_only(cli, oracle_cli):
-    # batches of a few records: results must not depend on where the reader cuts them
+@pytest.mark.parametrize("flags", [["-n"], ["-n", "-i"], ["-s", "-w", "0"], ["-n", "-s"], ["-q"], ["-m", "60", "-M", "90"]],
+                         ids=lambda v: " ".join(v))
+def test_seq_selection_flags_gpu_text(cli, oracle_cli, flags):
+    for f in ("hairpin.fa.gz", "reads_1.fq.gz"):
+        if flags == ["-q"] and f.endswith(".fa.gz"):
+            continue
+        want = run_cli(oracle_cli, ["seq"] + flags + [f])
+        got = run_cli(cli, ["seq"] + flags + [f])
+        assert got[0] == want[0] == 0 and got[1] == want[1], (f, flags)
+
+
+def test_seq_multiline_fastq(cli, oracle_cli):
+    text = "@r1\nACGT\nAC\n+\nIIII\nII\n"
+    rc, _, err = run_cli(cli, ["seq"], stdin=text)
+    assert rc == 255 and b"--host-parse" in err
+    want = run_cli(oracle_cli, ["seq", "-r", "-p"], stdin=text)
+    got = run_cli(cli, ["seq", "--host-parse", "-r", "-p"], stdin=text)
+    assert got[0] == want[0] == 0 and got[1] == want[1]
+
+
+@pytest.mark.parametrize("mode", MODES, ids=["gpu-text", "host-parse"])
+def test_seq_small_batches_and_qual_only(cli, oracle_cli, mode):
+    # batches / text blocks of a few records: results must not depend on where the input is cut
     for f in ("reads_1.fq.gz", "hairpin.fa.gz"):
         want = run_cli(oracle_cli, ["seq", "-r", "-p", f])
-        got = run_cli(cli, ["seq", "-r", "-p", "--batch-records", "7", "--batch-bytes", "1000", f])
+        got = run_cli(cli, ["seq"] + mode + ["-r", "-p", "--batch-records", "7", "--batch-bytes", "1000", f])
         assert got[1] == want[1]
     want = run_cli(oracle_cli, ["seq", "-r", "-q", "reads_2.fq.gz"])
-    got = run_cli(cli, ["seq", "-r", "-q", "reads_2.fq.gz"])
+    got = run_cli(cli, ["seq"] + mode + ["-r", "-q", "reads_2.fq.gz"])
     assert got[0] == 0 and got[1] == want[1]
-    rc, _, err = run_cli(cli, ["seq", "-q", "contigs.fa"])
+    rc, _, err = run_cli(cli, ["seq"] + mode + ["-q", "contigs.fa"])
     assert rc == 255 and b"[ERRO] FASTA format has no quality" in err
 
 
@@ -86,8 +113,9 @@ def test_stdin_edge_cases(cli, oracle_cli):
     cases = [">a\nATAT\n>b\n>c\nGGC\n", ">s\nAC-GT..A C\n", ">x\nacgtnACGTN\n", "@r\nAACGN\n+\n!#%&(\n",
              ">only\n", ">a\r\nAC\r\nGT\r\n>b\r\nTTTT", ">e1\n>e2\n>e3\nA\n"]
     for text in cases:
-        for argv in (["seq", "-r", "-p"], ["fx2tab", "-n", "-l", "-g", "-G", "-B", "AT"], ["stats", "-a", "-T"]):
-            want = run_cli(oracle_cli, argv, stdin=text)
+        for argv in (["seq", "-r", "-p"], ["seq", "--host-parse", "-r", "-p"],
+                     ["fx2tab", "-n", "-l", "-g", "-G", "-B", "AT"], ["stats", "-a", "-T"]):
+            want = run_cli(oracle_cli, [a for a in argv if a != "--host-parse"], stdin=text)
             got = run_cli(cli, argv, stdin=text)
             assert got[0] == want[0] and got[1] == want[1], (text, argv)
 
@@ -102,7 +130,9 @@ def test_long_records_through_the_driver(cli, oracle_cli, tmp_path):
             fh.write(b">r%d\n" % i)
             for a in range(0, n, 70):
                 fh.write(s[a:a + 70] + b"\n")
-    for argv in (["seq", "-r", "-p", str(p)], ["fx2tab", "-n", "-l", "-g", "-B", "AT", str(p)], ["stats", "-a", str(p)]):
-        want = run_cli(oracle_cli, argv)
+    for argv in (["seq", "-r", "-p", str(p)], ["seq", "--host-parse", "-r", "-p", str(p)],
+                 ["seq", "--batch-bytes", "65536", "-r", "-p", str(p)],          # blocks smaller than a record: they grow
+                 ["fx2tab", "-n", "-l", "-g", "-B", "AT", str(p)], ["stats", "-a", str(p)]):
+        want = run_cli(oracle_cli, [a for a in argv if a not in ("--host-parse", "--batch-bytes", "65536")])
         got = run_cli(cli, argv)
         assert got[0] == want[0] == 0 and got[1] == want[1]
