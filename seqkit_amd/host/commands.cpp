@@ -4,6 +4,8 @@
 // fx2tab.go:95-150, stat.go:86-161) but works a batch at a time: while the GPU transforms or
 // counts batch i, the host formats batch i-1 and parses batch i+1 (two pinned batches,
 // skh_*_submit / skh_batch_wait).
+#include <fcntl.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -36,12 +38,21 @@ class TextBlocks {
 public:
     TextBlocks(skh_ctx* ctx, const std::string& path, uint64_t block_bytes) : ctx_(ctx), path_(path)
     {
-        fh_ = path == "-" ? gzdopen(0, "rb") : gzopen(path.c_str(), "rb");
-        if (!fh_) { err_ = "open " + path + ": no such file or directory"; return; }
-        gzbuffer((gzFile)fh_, 1 << 20);
+        // plain files are read with read(2) straight into the pinned block; gzip (and stdin) through zlib
+        if (path != "-") {
+            fd_ = open(path.c_str(), O_RDONLY);
+            if (fd_ < 0) { err_ = "open " + path + ": no such file or directory"; return; }
+            unsigned char magic[2] = {0, 0};
+            const ssize_t got = pread(fd_, magic, 2, 0);
+            if (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) { fh_ = gzdopen(fd_, "rb"); fd_ = -1; }
+        } else {
+            fh_ = gzdopen(0, "rb");
+        }
+        if (fd_ < 0 && !fh_) { err_ = "open " + path + ": no such file or directory"; return; }
+        if (fh_) gzbuffer((gzFile)fh_, 1 << 20);
         if (skh_text_alloc(ctx, block_bytes, &t_) != SKH_OK) err_ = skh_last_error();
     }
-    ~TextBlocks() { if (fh_) gzclose((gzFile)fh_); if (t_) skh_text_free(t_); }
+    ~TextBlocks() { if (fh_) gzclose((gzFile)fh_); if (fd_ >= 0) close(fd_); if (t_) skh_text_free(t_); }
     bool ok() const { return err_.empty(); }
     const std::string& error() const { return err_; }
     bool is_fastq() const { return fastq_; }
@@ -57,7 +68,8 @@ public:
             const uint64_t cap = skh_text_capacity(t_);
             while (have_ < cap && !eof_) {
                 const uint64_t want = cap - have_ > (1u << 30) ? (1u << 30) : cap - have_;
-                const int n = gzread((gzFile)fh_, buf + have_, (unsigned)want);
+                const long n = fh_ ? (long)gzread((gzFile)fh_, buf + have_, (unsigned)want)
+                                   : (long)read(fd_, buf + have_, (size_t)want);
                 if (n < 0) { err_ = "read " + path_ + ": input error"; return false; }
                 if (n == 0) eof_ = true;
                 have_ += (uint64_t)n;
@@ -112,7 +124,7 @@ public:
 
 private:
     skh_ctx* ctx_; std::string path_, err_;
-    void* fh_ = nullptr; skh_text* t_ = nullptr;
+    void* fh_ = nullptr; int fd_ = -1; skh_text* t_ = nullptr;
     uint64_t have_ = 0, consumed_ = 0, lines_before_ = 0;
     bool eof_ = false, done_ = false, format_known_ = false, fastq_ = false, any_ = false;
 };
@@ -443,6 +455,35 @@ int64_t median(const int64_t* sorted, size_t l)      // stat.go:297-306
     return sorted[l / 2];
 }
 
+// one row of the table from a file's totals (stat.go:126-160); sorts `lens` when all is set
+StatInfo make_stat_info(const std::string& file, bool no_record, bool fastq_first, int ab, const skh_stats_partial& tot,
+                        std::vector<int64_t>& lens, bool all)
+{
+    StatInfo s;
+    s.file = file;
+    s.format = no_record ? "" : (fastq_first ? "FASTQ" : "FASTA");
+    s.type = ab == DNAredundant ? "DNA" : (ab == RNAredundant ? "RNA" : alphabet_name(ab));
+    s.len_max = tot.len_max;
+    if (tot.num != 0) {
+        s.num = tot.num; s.len_sum = tot.len_sum; s.gap_sum = tot.gap_sum; s.len_min = tot.len_min;
+        s.len_avg = round_to((double)tot.len_sum / (double)tot.num, 1);        // stat.go:158
+        if (all) {
+            std::sort(lens.begin(), lens.end());
+            int64_t sum = 0;                                                     // stat.go:138-145
+            for (size_t k = lens.size(); k-- > 0;) {
+                sum += lens[k];
+                if ((sum << 1) >= s.len_sum) { s.n50 = lens[k]; s.l50 = (int64_t)(lens.size() - k); break; }
+            }
+            const size_t l = lens.size();                                        // stat.go:308-326
+            const size_t c1 = l % 2 == 0 ? l / 2 : (l - 1) / 2, c2 = l % 2 == 0 ? l / 2 : c1 + 1;
+            s.q1 = median(lens.data(), c1);
+            s.q2 = median(lens.data(), l);
+            s.q3 = median(lens.data() + c2, l - c2);
+        }
+    }
+    return s;
+}
+
 }  // namespace
 
 int cmd_stats(const GlobalOpts& g, const StatsOpts& o, const std::vector<std::string>& files)
@@ -462,6 +503,40 @@ int cmd_stats(const GlobalOpts& g, const StatsOpts& o, const std::vector<std::st
     Batch bt;
     struct Free { Batch& b; ~Free() { if (b.b) skh_batch_free(b.b); } } guard{bt};
     for (const std::string& file : files) {
+        if (!g.host_parse) {
+            // file text parsed on the GPU: per block the totals kernel, and for -a the lengths
+            TextBlocks tb(ctx.c, file, g.batch_bytes);
+            if (!tb.ok()) return fatal(tb.error());
+            skh_stats_partial tot;
+            skh_stats_init(&tot);
+            std::vector<int64_t> lens;
+            std::vector<uint64_t> offs;
+            bool fastq_first = false, first = true;
+            int ab = -1;
+            skh_parse_result res;
+            while (tb.next(res)) {
+                skh_text* t = tb.block();
+                if (res.nrec == 0) { tb.advance(res); continue; }
+                if (first || o.all) {
+                    const uint64_t cnt = o.all ? res.nrec + 1 : 2;
+                    offs.resize(cnt);
+                    if (skh_text_offsets(ctx.c, t, 0, cnt, offs.data()) != SKH_OK) return fatal(skh_last_error());
+                }
+                if (first) {
+                    fastq_first = tb.is_fastq() && offs[1] > offs[0];                 // stat.go:107-113
+                    std::string err;
+                    ab = first_record_alphabet(ctx.c, t, g, -1, err);
+                    if (ab < 0) return fatal(err);
+                    first = false;
+                }
+                if (skh_text_stats(ctx.c, t, is_gap, &tot) != SKH_OK) return fatal(skh_last_error());
+                if (o.all) for (uint64_t r = 0; r < res.nrec; r++) lens.push_back((int64_t)(offs[r + 1] - offs[r]));
+                tb.advance(res);
+            }
+            if (!tb.error().empty()) return fatal(tb.error());
+            infos.push_back(make_stat_info(file, first, fastq_first, ab, tot, lens, o.all));
+            continue;
+        }
         FastxReader rd(ctx.c, file, Auto, g.guess_len);
         if (!rd.ok()) return fatal(rd.error());
         skh_stats_partial tot;
@@ -478,30 +553,7 @@ int cmd_stats(const GlobalOpts& g, const StatsOpts& o, const std::vector<std::st
             }
         }
         if (!rd.error().empty()) return fatal("error when parsing " + file + ": " + rd.error());
-        StatInfo s;
-        s.file = file;
-        s.format = first ? "" : (fastq_first ? "FASTQ" : "FASTA");
-        const int ab = rd.alphabet();
-        s.type = ab == DNAredundant ? "DNA" : (ab == RNAredundant ? "RNA" : alphabet_name(ab));
-        s.len_max = tot.len_max;
-        if (tot.num != 0) {
-            s.num = tot.num; s.len_sum = tot.len_sum; s.gap_sum = tot.gap_sum; s.len_min = tot.len_min;
-            s.len_avg = round_to((double)tot.len_sum / (double)tot.num, 1);        // stat.go:158
-            if (o.all) {
-                std::sort(lens.begin(), lens.end());
-                int64_t sum = 0;                                                     // stat.go:138-145
-                for (size_t k = lens.size(); k-- > 0;) {
-                    sum += lens[k];
-                    if ((sum << 1) >= s.len_sum) { s.n50 = lens[k]; s.l50 = (int64_t)(lens.size() - k); break; }
-                }
-                const size_t l = lens.size();                                        // stat.go:308-326
-                const size_t c1 = l % 2 == 0 ? l / 2 : (l - 1) / 2, c2 = l % 2 == 0 ? l / 2 : c1 + 1;
-                s.q1 = median(lens.data(), c1);
-                s.q2 = median(lens.data(), l);
-                s.q3 = median(lens.data() + c2, l - c2);
-            }
-        }
-        infos.push_back(s);
+        infos.push_back(make_stat_info(file, first, fastq_first, rd.alphabet(), tot, lens, o.all));
     }
 
     char line[8192];

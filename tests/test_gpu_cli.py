@@ -102,11 +102,14 @@ def test_fx2tab_float_trap(cli):
     assert rows[b"tcc-MIR172b"][3:] == [b"160", b"41.87"] and rows[b"cme-MIR167a"][3:] == [b"160", b"41.87"]
 
 
+@pytest.mark.parametrize("mode", MODES, ids=["gpu-text", "host-parse"])
 @pytest.mark.parametrize("flags", [[], ["-T"], ["-a"], ["-a", "-T"], ["-a", "-G", "N"]], ids=lambda v: " ".join(v) or "plain")
-def test_stats_matches_oracle(cli, oracle_cli, flags):
+def test_stats_matches_oracle(cli, oracle_cli, flags, mode):
     want = run_cli(oracle_cli, ["stats"] + flags + FILES)
-    got = run_cli(cli, ["stats"] + flags + FILES)
+    got = run_cli(cli, ["stats"] + mode + flags + FILES)
     assert got[0] == want[0] == 0 and got[1] == want[1]
+    got = run_cli(cli, ["stats"] + mode + ["--batch-bytes", "20000"] + flags + FILES)     # many blocks per file
+    assert got[0] == 0 and got[1] == want[1]
 
 
 def test_stdin_edge_cases(cli, oracle_cli):
@@ -114,7 +117,8 @@ def test_stdin_edge_cases(cli, oracle_cli):
              ">only\n", ">a\r\nAC\r\nGT\r\n>b\r\nTTTT", ">e1\n>e2\n>e3\nA\n"]
     for text in cases:
         for argv in (["seq", "-r", "-p"], ["seq", "--host-parse", "-r", "-p"],
-                     ["fx2tab", "-n", "-l", "-g", "-G", "-B", "AT"], ["stats", "-a", "-T"]):
+                     ["fx2tab", "-n", "-l", "-g", "-G", "-B", "AT"], ["stats", "-a", "-T"],
+                     ["stats", "--host-parse", "-a", "-T"]):
             want = run_cli(oracle_cli, [a for a in argv if a != "--host-parse"], stdin=text)
             got = run_cli(cli, argv, stdin=text)
             assert got[0] == want[0] and got[1] == want[1], (text, argv)
@@ -132,7 +136,8 @@ def test_long_records_through_the_driver(cli, oracle_cli, tmp_path):
                 fh.write(s[a:a + 70] + b"\n")
     for argv in (["seq", "-r", "-p", str(p)], ["seq", "--host-parse", "-r", "-p", str(p)],
                  ["seq", "--batch-bytes", "65536", "-r", "-p", str(p)],          # blocks smaller than a record: they grow
-                 ["fx2tab", "-n", "-l", "-g", "-B", "AT", str(p)], ["stats", "-a", str(p)]):
+                 ["fx2tab", "-n", "-l", "-g", "-B", "AT", str(p)], ["stats", "-a", str(p)],
+                 ["stats", "--host-parse", "-a", str(p)]):
         want = run_cli(oracle_cli, [a for a in argv if a not in ("--host-parse", "--batch-bytes", "65536")])
         got = run_cli(cli, argv)
         assert got[0] == want[0] == 0 and got[1] == want[1]
