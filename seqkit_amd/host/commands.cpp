@@ -9,6 +9,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <chrono>
 #include <climits>
 #include <cstring>
 
@@ -26,6 +27,24 @@ struct Ctx {
 struct TwoBatches {
     Batch bt[2];
     ~TwoBatches() { for (auto& b : bt) if (b.b) skh_batch_free(b.b); }
+};
+
+// ---- phase timing (SKH_TIMING=1: totals on stderr at exit) ---------------------------------
+struct Phases {
+    double t[6] = {0, 0, 0, 0, 0, 0};
+    bool on = getenv("SKH_TIMING") != nullptr;
+    static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+    ~Phases()
+    {
+        if (on) fprintf(stderr, "[timing] read %.3f s, upload+parse %.3f s, kernels %.3f s, format+download %.3f s, "
+                                "write %.3f s, buffer alloc/free %.3f s\n", t[0], t[1], t[2], t[3], t[4], t[5]);
+    }
+};
+Phases g_phases;
+struct PhaseTimer {
+    int k; double t0;
+    explicit PhaseTimer(int k_) : k(k_), t0(g_phases.on ? Phases::now() : 0) {}
+    ~PhaseTimer() { if (g_phases.on) g_phases.t[k] += Phases::now() - t0; }
 };
 
 // ---- file text in blocks, parsed on the GPU ------------------------------------------------
@@ -50,9 +69,11 @@ public:
         }
         if (fd_ < 0 && !fh_) { err_ = "open " + path + ": no such file or directory"; return; }
         if (fh_) gzbuffer((gzFile)fh_, 1 << 20);
+        PhaseTimer pt(5);
         if (skh_text_alloc(ctx, block_bytes, &t_) != SKH_OK) err_ = skh_last_error();
     }
-    ~TextBlocks() { if (fh_) gzclose((gzFile)fh_); if (fd_ >= 0) close(fd_); if (t_) skh_text_free(t_); }
+    ~TextBlocks() {
+        PhaseTimer pt(5); if (fh_) gzclose((gzFile)fh_); if (fd_ >= 0) close(fd_); if (t_) skh_text_free(t_); }
     bool ok() const { return err_.empty(); }
     const std::string& error() const { return err_; }
     bool is_fastq() const { return fastq_; }
@@ -67,6 +88,7 @@ public:
             uint8_t* buf = skh_text_buffer(t_);
             const uint64_t cap = skh_text_capacity(t_);
             while (have_ < cap && !eof_) {
+                PhaseTimer pt(0);
                 const uint64_t want = cap - have_ > (1u << 30) ? (1u << 30) : cap - have_;
                 const long n = fh_ ? (long)gzread((gzFile)fh_, buf + have_, (unsigned)want)
                                    : (long)read(fd_, buf + have_, (size_t)want);
@@ -86,6 +108,7 @@ public:
                 format_known_ = true;
                 if (have_ < cap && !eof_) continue;                        // top the block up again
             }
+            PhaseTimer pt(1);
             if (skh_text_parse(ctx_, t_, have_, fastq_ ? SKH_FASTQ : SKH_FASTA, eof_, &res) != SKH_OK) {
                 err_ = skh_last_error();
                 return false;
@@ -115,11 +138,10 @@ public:
     void advance(const skh_parse_result& res)
     {
         uint8_t* buf = skh_text_buffer(t_);
-        for (uint64_t k = 0; k < consumed_; k++) lines_before_ += buf[k] == '\n';
+        lines_before_ += fastq_ ? res.nrec * 4 : res.lines;      // for error messages ("near line")
         memmove(buf, buf + consumed_, have_ - consumed_);
         have_ -= consumed_;
         consumed_ = 0;
-        (void)res;
     }
 
 private:
@@ -148,7 +170,7 @@ int seq_text_path(const GlobalOpts& g, const SeqOpts& o, const std::vector<std::
     bool is_fastq = false, check_type = true;        // seq.go:105-106: decided once, by the first printed record
     std::vector<uint64_t> offs;
     for (const std::string& file : files) {
-        TextBlocks tb(ctx, file, g.batch_bytes);
+        TextBlocks tb(ctx, file, g.text_block_bytes);
         if (!tb.ok()) return fatal(tb.error());
         uint8_t lut[256];
         bool lut_ready = false;
@@ -167,6 +189,7 @@ int seq_text_path(const GlobalOpts& g, const SeqOpts& o, const std::vector<std::
             }
             if (o.reverse || o.complement) {
                 // seq.go:187-195: ReverseInplace (bases and qualities), then ComplementInplace
+                PhaseTimer pt(2);
                 if (skh_text_revcomp(ctx, t, o.complement ? lut : nullptr, o.reverse, 1) != SKH_OK) return fatal(skh_last_error());
             }
             if (check_type) {
@@ -199,7 +222,11 @@ int seq_text_path(const GlobalOpts& g, const SeqOpts& o, const std::vector<std::
                 f.mark = is_fastq ? '@' : '>';
                 const uint8_t* text = nullptr;
                 uint64_t nbytes = 0;
-                if (skh_text_format_seq(ctx, t, &f, &text, &nbytes) != SKH_OK) return fatal(skh_last_error());
+                {
+                    PhaseTimer pt(3);
+                    if (skh_text_format_seq(ctx, t, &f, &text, &nbytes) != SKH_OK) return fatal(skh_last_error());
+                }
+                PhaseTimer pt(4);
                 out.write(text, nbytes);
             }
             tb.advance(res);
@@ -215,7 +242,9 @@ int seq_text_path(const GlobalOpts& g, const SeqOpts& o, const std::vector<std::
 int cmd_seq(const GlobalOpts& g, const SeqOpts& o, const std::vector<std::string>& files)
 {
     Ctx ctx;
+    const double t_init = Phases::now();
     if (skh_init(g.device, &ctx.c) != SKH_OK) return fatal(skh_last_error());
+    if (g_phases.on) fprintf(stderr, "[timing] skh_init %.3f s\n", Phases::now() - t_init);
     Sink out(g.out_file);
     if (!out.ok()) return fatal("open " + g.out_file + ": cannot create");
     if (!g.host_parse) return seq_text_path(g, o, files, ctx.c, out);
@@ -505,7 +534,7 @@ int cmd_stats(const GlobalOpts& g, const StatsOpts& o, const std::vector<std::st
     for (const std::string& file : files) {
         if (!g.host_parse) {
             // file text parsed on the GPU: per block the totals kernel, and for -a the lengths
-            TextBlocks tb(ctx.c, file, g.batch_bytes);
+            TextBlocks tb(ctx.c, file, g.text_block_bytes);
             if (!tb.ok()) return fatal(tb.error());
             skh_stats_partial tot;
             skh_stats_init(&tot);

@@ -98,6 +98,7 @@ struct GlobalOpts {
     size_t guess_len = 10000;     // --alphabet-guess-seq-length
     int device = 0;               // --device (extension: which GPU)
     uint64_t batch_bytes = 256ull << 20, batch_records = 4ull << 20;
+    uint64_t text_block_bytes = 32ull << 20;   // text path: file bytes per block (--batch-bytes overrides)
     bool host_parse = false;      // --host-parse: records are scanned and printed by the host
                                   // (needed for multi-line FASTQ); default: file text is parsed
                                   // and, for seq, formatted on the GPU

@@ -144,6 +144,7 @@ int main(int argc, char** argv)
     g.batch_bytes = strtoull(p.value("batch-bytes", "268435456").c_str(), nullptr, 10);
     g.batch_records = strtoull(p.value("batch-records", "4194304").c_str(), nullptr, 10);
     g.host_parse = p.has("host-parse");
+    if (p.has("batch-bytes")) g.text_block_bytes = g.batch_bytes;
     if (p.has("id-regexp") || p.has("id-ncbi"))
         return fatal("--id-regexp / --id-ncbi are not supported by this driver (default ID rule only)");
     std::vector<std::string> files = p.args;
