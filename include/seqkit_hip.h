@@ -192,6 +192,38 @@ int skh_format_seq_dev(skh_ctx *ctx, const uint8_t *d_text, const uint64_t *d_na
                        uint8_t *d_out, uint64_t out_capacity, void *d_workspace,
                        uint64_t workspace_bytes, skh_format_result *d_result, void *stream);
 
+/* fx2tab rows on the device (seqkit/cmd/fx2tab.go:112-148): per record
+ *     name-or-ID '\t' [sequence] '\t' [quality] { '\t' number } '\n'
+ * with one number per column: the length ("%d"), GC content and GC skew ("%.2f" of
+ * (g+c)*100 and (g-c)/(g+c)*100 where g and c are divided by the length separately,
+ * fx2tab.go:128-133), or the content of a letter list ("%.2f" of sum/len*100; 0 for an
+ * empty sequence; "NaN" prints as Go prints it).  The letter counts come from up to
+ * SKH_TAB_MAX_PASSES skh_count_dev results (d_counts[p] is nrec x nclass[p]); a term names
+ * a letter's count as pass * 8 + class. */
+#define SKH_TAB_MAX_COLS   16
+#define SKH_TAB_MAX_TERMS  30
+#define SKH_TAB_MAX_PASSES 4
+#define SKH_TAB_LENGTH  0
+#define SKH_TAB_GC      1   /* term[0] = G, term[1] = C */
+#define SKH_TAB_GC_SKEW 2   /* term[0] = G, term[1] = C */
+#define SKH_TAB_CONTENT 3   /* nterm letters, repeated letters count again */
+typedef struct skh_tab_column {
+    uint8_t kind, nterm;
+    uint8_t term[SKH_TAB_MAX_TERMS];
+} skh_tab_column;
+typedef struct skh_tab_format {
+    uint32_t ncols;
+    uint8_t only_id, print_seq, print_qual, reserved;
+    skh_tab_column cols[SKH_TAB_MAX_COLS];
+} skh_tab_format;
+int skh_format_tab_dev(skh_ctx *ctx, const uint8_t *d_text, const uint64_t *d_name_pos,
+                       const uint32_t *d_name_len, const uint8_t *d_seq, const uint8_t *d_qual,
+                       const uint64_t *d_offsets, uint64_t nrec,
+                       const uint64_t *const d_counts[SKH_TAB_MAX_PASSES],
+                       const uint32_t nclass[SKH_TAB_MAX_PASSES], const skh_tab_format *fmt,
+                       uint8_t *d_out, uint64_t out_capacity, void *d_workspace,
+                       uint64_t workspace_bytes, skh_format_result *d_result, void *stream);
+
 /* ---- text blocks: file text in, file text out ----------------------------------------
  * The library-owned form of the two entry points above, for callers that hold file text
  * in host memory (what a cgo shim or the C++ driver uses instead of a record reader):
@@ -219,6 +251,12 @@ int skh_text_revcomp(skh_ctx *ctx, skh_text *t, const uint8_t *lut, int do_rever
 /* skh_format_seq_dev + download: *out points at out_bytes of pinned memory owned by the
  * block, valid until its next call. */
 int skh_text_format_seq(skh_ctx *ctx, skh_text *t, const skh_seq_format *fmt,
+                        const uint8_t **out, uint64_t *out_bytes);
+/* skh_count_dev on the block; the counts stay on the device in slot `pass`
+ * (< SKH_TAB_MAX_PASSES) for skh_text_format_tab. */
+int skh_text_count(skh_ctx *ctx, skh_text *t, const uint8_t class_of[256], uint32_t nclass, uint32_t pass);
+/* skh_format_tab_dev on the block with the counts of the passes run so far + download. */
+int skh_text_format_tab(skh_ctx *ctx, skh_text *t, const skh_tab_format *fmt,
                         const uint8_t **out, uint64_t *out_bytes);
 /* skh_stats_dev on the block, merged into *inout. */
 int skh_text_stats(skh_ctx *ctx, skh_text *t, const uint8_t is_gap[256], skh_stats_partial *inout);

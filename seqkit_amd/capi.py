@@ -31,6 +31,18 @@ class SeqFormat(C.Structure):
                 ("plus_line", C.c_uint8), ("only_id", C.c_uint8), ("mark", C.c_char)]
 
 
+class TabColumn(C.Structure):
+    _fields_ = [("kind", C.c_uint8), ("nterm", C.c_uint8), ("term", C.c_uint8 * 30)]
+
+
+class TabFormat(C.Structure):
+    _fields_ = [("ncols", C.c_uint32), ("only_id", C.c_uint8), ("print_seq", C.c_uint8), ("print_qual", C.c_uint8),
+                ("reserved", C.c_uint8), ("cols", TabColumn * 16)]
+
+
+TAB_LENGTH, TAB_GC, TAB_GC_SKEW, TAB_CONTENT = 0, 1, 2, 3
+
+
 class FormatResult(C.Structure):
     _fields_ = [("out_bytes", C.c_uint64), ("status", C.c_uint32), ("reserved", C.c_uint32)]
 
@@ -57,6 +69,10 @@ SYMBOLS = {
     "skh_format_workspace_size": (C.c_uint64, [C.c_uint64]),
     "skh_format_seq_dev": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_uint64, C.POINTER(SeqFormat), vp, C.c_uint64,
                                      vp, C.c_uint64, vp, vp]),
+    "skh_format_tab_dev": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_uint64, C.POINTER(vp), C.POINTER(C.c_uint32),
+                                     C.POINTER(TabFormat), vp, C.c_uint64, vp, C.c_uint64, vp, vp]),
+    "skh_text_count": (C.c_int, [vp, vp, u8p, C.c_uint32, C.c_uint32]),
+    "skh_text_format_tab": (C.c_int, [vp, vp, C.POINTER(TabFormat), C.POINTER(vp), u64p]),
     "skh_text_alloc": (C.c_int, [vp, C.c_uint64, C.POINTER(vp)]),
     "skh_text_free": (None, [vp]),
     "skh_text_buffer": (vp, [vp]),

@@ -383,6 +383,50 @@ int skh_format_seq_dev(skh_ctx* ctx, const uint8_t* d_text, const uint64_t* d_na
     return SKH_OK;
 }
 
+int skh_format_tab_dev(skh_ctx* ctx, const uint8_t* d_text, const uint64_t* d_name_pos, const uint32_t* d_name_len,
+                       const uint8_t* d_seq, const uint8_t* d_qual, const uint64_t* d_offsets, uint64_t nrec,
+                       const uint64_t* const d_counts[SKH_TAB_MAX_PASSES], const uint32_t nclass[SKH_TAB_MAX_PASSES],
+                       const skh_tab_format* fmt, uint8_t* d_out, uint64_t out_capacity, void* d_workspace,
+                       uint64_t workspace_bytes, skh_format_result* d_result, void* stream)
+{
+    static_assert(sizeof(skh_tab_column) == sizeof(skh::TabColumn), "layout");
+    static_assert(SKH_TAB_MAX_COLS == skh::TAB_MAX_COLS && SKH_TAB_MAX_TERMS == skh::TAB_MAX_TERMS &&
+                  SKH_TAB_MAX_PASSES == skh::TAB_MAX_PASSES, "limits");
+    if (!ctx) return fail(SKH_EINVAL, "ctx is NULL");
+    if (!fmt || !d_offsets || !d_workspace || !d_result || !d_counts || !nclass) return fail(SKH_EINVAL, "NULL argument");
+    if (nrec != 0 && (!d_out || !d_text || !d_name_pos || !d_name_len)) return fail(SKH_EINVAL, "NULL buffer");
+    if (fmt->print_seq && nrec != 0 && !d_seq) return fail(SKH_EINVAL, "sequence requested without a sequence plane");
+    if (fmt->print_qual && nrec != 0 && !d_qual) return fail(SKH_EINVAL, "quality requested without a quality plane");
+    if (fmt->ncols > SKH_TAB_MAX_COLS) return fail(SKH_EINVAL, "too many columns");
+    if (reinterpret_cast<uintptr_t>(d_workspace) & 255) return fail(SKH_EINVAL, "workspace is not 256-byte aligned");
+    if (workspace_bytes < skh::format_workspace_size(nrec))
+        return fail(SKH_ECAPACITY, "workspace smaller than skh_format_workspace_size(nrec)");
+    skh::FormatTabArgs a;
+    memset(&a, 0, sizeof a);
+    a.text = d_text; a.name_pos = d_name_pos; a.name_len = d_name_len; a.seq = d_seq; a.qual = d_qual;
+    a.offsets = d_offsets; a.nrec = nrec;
+    for (int p = 0; p < SKH_TAB_MAX_PASSES; p++) { a.counts[p] = d_counts[p]; a.nclass[p] = nclass[p]; }
+    a.ncols = fmt->ncols;
+    a.only_id = fmt->only_id != 0; a.print_seq = fmt->print_seq != 0; a.print_qual = fmt->print_qual != 0;
+    for (uint32_t c = 0; c < fmt->ncols; c++) {
+        const skh_tab_column& col = fmt->cols[c];
+        if (col.kind > SKH_TAB_CONTENT) return fail(SKH_EINVAL, "unknown column kind");
+        const uint32_t nterm = col.kind == SKH_TAB_LENGTH ? 0 : (col.kind == SKH_TAB_CONTENT ? col.nterm : 2);
+        if (nterm > SKH_TAB_MAX_TERMS) return fail(SKH_EINVAL, "too many letters in a column");
+        for (uint32_t k = 0; k < nterm; k++) {
+            const uint32_t pass = col.term[k] >> 3, cls = col.term[k] & 7;
+            if (pass >= SKH_TAB_MAX_PASSES || !d_counts[pass] || cls >= nclass[pass])
+                return fail(SKH_EINVAL, "a column names a count that was not supplied");
+        }
+        a.cols[c].kind = col.kind; a.cols[c].nterm = (uint8_t)nterm;
+        memcpy(a.cols[c].term, col.term, sizeof col.term);
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    HIP_TRY(skh::launch_format_tab(a, d_out, out_capacity, d_workspace, reinterpret_cast<skh::FormatResult*>(d_result), st));
+    return SKH_OK;
+}
+
 // ---------------------------------------------------------------- pinned batches
 
 int skh_batch_alloc(skh_ctx* ctx, uint64_t max_bytes, uint64_t max_records, int with_qual, skh_batch** out)
@@ -606,6 +650,9 @@ struct skh_text {
     int fastq = 0;
     uint64_t nrec = 0, seq_bytes = 0, text_bytes = 0;
     bool transformed = false;               // planes of the block now live in d_seq2 / d_qual2
+    uint64_t* d_counts[SKH_TAB_MAX_PASSES] = {nullptr, nullptr, nullptr, nullptr};   // results of skh_text_count
+    uint64_t counts_cap[SKH_TAB_MAX_PASSES] = {0, 0, 0, 0};
+    uint32_t nclass[SKH_TAB_MAX_PASSES] = {0, 0, 0, 0};
 };
 
 namespace {
@@ -679,6 +726,7 @@ void skh_text_free(skh_text* t)
     text_free_lines(t);
     (void)hipFree(t->d_text); (void)hipFree(t->d_seq); (void)hipFree(t->d_qual); (void)hipFree(t->d_seq2); (void)hipFree(t->d_qual2);
     (void)hipFree(t->d_out); (void)hipFree(t->d_res);
+    for (auto& c : t->d_counts) (void)hipFree(c);
     (void)hipHostFree(t->h_text); (void)hipHostFree(t->h_out); (void)hipHostFree(t->h_res);
     delete t;
 }
@@ -765,6 +813,54 @@ int skh_text_format_seq(skh_ctx* ctx, skh_text* t, const skh_seq_format* fmt, co
         int rc = skh_format_seq_dev(ctx, t->d_text, t->d_npos, t->d_nlen, seq, qual, t->d_offs, t->nrec, fmt, t->d_out,
                                     t->out_cap, t->d_fws, t->fws_bytes, static_cast<skh_format_result*>(t->d_res),
                                     t->stream);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(t->h_res, t->d_res, sizeof(skh_format_result), hipMemcpyDeviceToHost, t->stream));
+        HIP_TRY(hipStreamSynchronize(t->stream));
+        const skh_format_result r = *static_cast<skh_format_result*>(t->h_res);
+        if (r.status == SKH_PARSE_OK) {
+            HIP_TRY(hipMemcpyAsync(t->h_out, t->d_out, r.out_bytes, hipMemcpyDeviceToHost, t->stream));
+            HIP_TRY(hipStreamSynchronize(t->stream));
+            *out = t->h_out;
+            *out_bytes = r.out_bytes;
+            return SKH_OK;
+        }
+        hipError_t e = text_alloc_out(t, r.out_bytes + r.out_bytes / 16 + 4096);
+        if (e != hipSuccess) return hip_fail(e, "growing the output buffer");
+    }
+}
+
+int skh_text_count(skh_ctx* ctx, skh_text* t, const uint8_t class_of[256], uint32_t nclass, uint32_t pass)
+{
+    if (!ctx || !t || !class_of) return fail(SKH_EINVAL, "NULL argument");
+    if (pass >= SKH_TAB_MAX_PASSES) return fail(SKH_EINVAL, "pass out of range");
+    if (nclass < 1 || nclass > SKH_MAX_CLASSES) return fail(SKH_EINVAL, "nclass out of range");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const uint64_t need = (t->nrec ? t->nrec : 1) * nclass * 8;
+    if (t->counts_cap[pass] < need) {
+        (void)hipFree(t->d_counts[pass]);
+        t->d_counts[pass] = nullptr; t->counts_cap[pass] = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&t->d_counts[pass]), need + need / 4));
+        t->counts_cap[pass] = need + need / 4;
+    }
+    t->nclass[pass] = nclass;
+    if (t->nrec == 0) return SKH_OK;
+    return skh_count_dev(ctx, t->transformed ? t->d_seq2 : t->d_seq, t->d_offs, t->nrec, t->seq_bytes, class_of, nclass,
+                         t->d_counts[pass], t->stream);
+}
+
+int skh_text_format_tab(skh_ctx* ctx, skh_text* t, const skh_tab_format* fmt, const uint8_t** out, uint64_t* out_bytes)
+{
+    if (!ctx || !t || !fmt || !out || !out_bytes) return fail(SKH_EINVAL, "NULL argument");
+    *out = nullptr; *out_bytes = 0;
+    if (t->nrec == 0) return SKH_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const uint8_t* seq = t->transformed ? t->d_seq2 : t->d_seq;
+    const uint8_t* qual = t->fastq ? (t->transformed ? t->d_qual2 : t->d_qual) : nullptr;
+    if (fmt->print_qual && !qual) return fail(SKH_EINVAL, "quality requested for a FASTA block");
+    for (;;) {
+        int rc = skh_format_tab_dev(ctx, t->d_text, t->d_npos, t->d_nlen, seq, qual, t->d_offs, t->nrec, t->d_counts,
+                                    t->nclass, fmt, t->d_out, t->out_cap, t->d_fws, t->fws_bytes,
+                                    static_cast<skh_format_result*>(t->d_res), t->stream);
         if (rc) return rc;
         HIP_TRY(hipMemcpyAsync(t->h_res, t->d_res, sizeof(skh_format_result), hipMemcpyDeviceToHost, t->stream));
         HIP_TRY(hipStreamSynchronize(t->stream));

@@ -185,6 +185,137 @@ __global__ __launch_bounds__(FB) void k_fmt_write(const FormatSeqArgs a, const u
     }
 }
 
+// ---- fx2tab rows ------------------------------------------------------------------------------
+
+// "%.2f" of v, exactly as C and Go print it: the binary value is rounded to hundredths with
+// ties to even on the exact value (integer arithmetic; |v| < 2^52 here: percentages).
+// Returns the number of characters written to buf (at most 24).
+__device__ __forceinline__ uint32_t fmt_fixed2(double v, char* buf)
+{
+    const uint64_t bits = (uint64_t)__double_as_longlong(v);
+    const bool neg = (bits >> 63) != 0;
+    const uint32_t E = (uint32_t)((bits >> 52) & 0x7ff);
+    const uint64_t frac = bits & ((1ull << 52) - 1);
+    if (E == 0x7ff) {
+        if (frac) { buf[0] = 'N'; buf[1] = 'a'; buf[2] = 'N'; return 3; }
+        buf[0] = neg ? '-' : '+'; buf[1] = 'I'; buf[2] = 'n'; buf[3] = 'f'; return 4;
+    }
+    // |v| = m * 2^-sh
+    const uint64_t m = E ? (frac | (1ull << 52)) : frac;
+    const int sh = E ? 1075 - (int)E : 1074;
+    uint64_t q = 0;                                   // |v| * 100 rounded to an integer
+    const uint64_t P = m * 100;                       // < 2^60
+    if (sh <= 0) q = P << (-sh);                      // not reached for percentages (|v| >= 2^52)
+    else if (sh < 64) {
+        q = P >> sh;
+        const uint64_t rem = P & ((1ull << sh) - 1), half = 1ull << (sh - 1);
+        if (rem > half || (rem == half && (q & 1))) q++;
+    }
+    uint32_t n = 0;
+    if (neg) buf[n++] = '-';
+    uint64_t ip = q / 100;
+    const uint32_t fp = (uint32_t)(q % 100);
+    char tmp[20];
+    uint32_t k = 0;
+    do { tmp[k++] = (char)('0' + ip % 10); ip /= 10; } while (ip);
+    while (k) buf[n++] = tmp[--k];
+    buf[n++] = '.';
+    buf[n++] = (char)('0' + fp / 10);
+    buf[n++] = (char)('0' + fp % 10);
+    return n;
+}
+
+__device__ __forceinline__ uint32_t fmt_u64(uint64_t v, char* buf)
+{
+    char tmp[20];
+    uint32_t k = 0, n = 0;
+    do { tmp[k++] = (char)('0' + v % 10); v /= 10; } while (v);
+    while (k) buf[n++] = tmp[--k];
+    return n;
+}
+
+constexpr uint32_t TAB_NUM_MAX = 26 * TAB_MAX_COLS;     // characters of all numeric columns of a row
+
+__device__ __forceinline__ uint64_t tab_term_sum(const FormatTabArgs& a, const TabColumn& c, uint64_t r)
+{
+    uint64_t sum = 0;
+    for (uint32_t k = 0; k < c.nterm; k++) {
+        const uint32_t pass = c.term[k] >> 3, cls = c.term[k] & 7;
+        sum += a.counts[pass][r * a.nclass[pass] + cls];
+    }
+    return sum;
+}
+
+// the numeric columns of record r ("\t<number>" each), as fx2tab.go:127-143 prints them
+__device__ uint32_t tab_numbers(const FormatTabArgs& a, uint64_t r, uint64_t len, char* buf)
+{
+    uint32_t n = 0;
+    double gg = 0, cc = 0;
+    bool have_gc = false;
+    for (uint32_t ci = 0; ci < a.ncols; ci++) {
+        const TabColumn& c = a.cols[ci];
+        buf[n++] = '\t';
+        if (c.kind == TAB_LENGTH) { n += fmt_u64(len, buf + n); continue; }
+        if (c.kind == TAB_CONTENT) {
+            const double v = len ? (double)tab_term_sum(a, c, r) / (double)len : 0.0;
+            n += fmt_fixed2(v * 100, buf + n);
+            continue;
+        }
+        if (!have_gc) {
+            // two separate divisions, then the sum (fx2tab.go:128-133)
+            const uint32_t pg = c.term[0] >> 3, kg = c.term[0] & 7, pc = c.term[1] >> 3, kc = c.term[1] & 7;
+            gg = len ? (double)a.counts[pg][r * a.nclass[pg] + kg] / (double)len : 0.0;
+            cc = len ? (double)a.counts[pc][r * a.nclass[pc] + kc] / (double)len : 0.0;
+            have_gc = true;
+        }
+        if (c.kind == TAB_GC) n += fmt_fixed2((gg + cc) * 100, buf + n);
+        else n += fmt_fixed2((gg - cc) / (gg + cc) * 100, buf + n);
+    }
+    return n;
+}
+
+__global__ __launch_bounds__(FB) void k_tab_sizes(const FormatTabArgs a, uint64_t* __restrict__ size,
+                                                  uint32_t* __restrict__ shown_name)
+{
+    for (uint64_t r = (uint64_t)blockIdx.x * FB + threadIdx.x; r < a.nrec; r += (uint64_t)gridDim.x * FB) {
+        const uint64_t len = a.offsets[r + 1] - a.offsets[r];
+        uint32_t nl = a.name_len[r];
+        if (a.only_id) nl = id_length(a.text + a.name_pos[r], nl);
+        char buf[TAB_NUM_MAX];
+        const uint32_t nn = tab_numbers(a, r, len, buf);
+        size[r] = (uint64_t)nl + 1 + (a.print_seq ? len : 0) + 1 + (a.print_qual ? len : 0) + nn + 1;
+        shown_name[r] = nl;
+    }
+}
+
+__global__ __launch_bounds__(FB) void k_tab_write(const FormatTabArgs a, const uint64_t* __restrict__ pos,
+                                                  const uint32_t* __restrict__ shown_name,
+                                                  const uint64_t* __restrict__ total, uint8_t* __restrict__ out,
+                                                  uint64_t out_capacity)
+{
+    constexpr uint32_t G = 16;
+    if (*total > out_capacity) return;
+    const uint32_t j = threadIdx.x & (G - 1);
+    for (uint64_t r = ((uint64_t)blockIdx.x * FB + threadIdx.x) / G; r < a.nrec; r += (uint64_t)gridDim.x * (FB / G)) {
+        uint8_t* o = out + pos[r];
+        const uint64_t s = a.offsets[r], len = a.offsets[r + 1] - s;
+        const uint32_t nl = shown_name[r];
+        copy_plain<G>(o, a.text + a.name_pos[r], nl, j);
+        if (j == 0) o[nl] = '\t';
+        o += nl + 1;
+        if (a.print_seq) { copy_plain<G>(o, a.seq + s, len, j); o += len; }
+        if (j == 0) *o = '\t';
+        o++;
+        if (a.print_qual) { copy_plain<G>(o, a.qual + s, len, j); o += len; }
+        if (j == G - 1) {                       // the lane with the least copying to do
+            char buf[TAB_NUM_MAX];
+            const uint32_t nn = tab_numbers(a, r, len, buf);
+            for (uint32_t k = 0; k < nn; k++) o[k] = (uint8_t)buf[k];
+            o[nn] = '\n';
+        }
+    }
+}
+
 __global__ void k_fmt_finish(const uint64_t* __restrict__ total, uint64_t out_capacity, FormatResult* __restrict__ res)
 {
     res->out_bytes = *total;
@@ -219,6 +350,27 @@ hipError_t launch_format_seq(const FormatSeqArgs& a, uint8_t* out, uint64_t out_
     hipLaunchKernelGGL(k_scan_apply64, dim3((uint32_t)npart), dim3(FB), 0, s, size, a.nrec, part, pos);
     hipLaunchKernelGGL(k_fmt_write, dim3(capped((a.nrec * 16 + FB - 1) / FB)), dim3(FB), 0, s, a, size, pos, shown, total,
                        out, out_capacity);
+    hipLaunchKernelGGL(k_fmt_finish, dim3(1), dim3(1), 0, s, total, out_capacity, res);
+    return hipGetLastError();
+}
+
+hipError_t launch_format_tab(const FormatTabArgs& a, uint8_t* out, uint64_t out_capacity, void* workspace,
+                             FormatResult* res, hipStream_t s)
+{
+    uint8_t* ws = static_cast<uint8_t*>(workspace);
+    uint64_t* total = reinterpret_cast<uint64_t*>(ws); ws += up256(8);
+    uint64_t* size = reinterpret_cast<uint64_t*>(ws); ws += up256(a.nrec * 8);
+    uint64_t* pos = reinterpret_cast<uint64_t*>(ws); ws += up256(a.nrec * 8);
+    uint32_t* shown = reinterpret_cast<uint32_t*>(ws); ws += up256(a.nrec * 4);
+    uint64_t* part = reinterpret_cast<uint64_t*>(ws);
+    const uint64_t npart = (a.nrec + FSCAN_TILE - 1) / FSCAN_TILE ? (a.nrec + FSCAN_TILE - 1) / FSCAN_TILE : 1;
+    auto capped = [](uint64_t b) { return (uint32_t)(b < 1 ? 1 : (b > 16384 ? 16384 : b)); };
+    hipLaunchKernelGGL(k_tab_sizes, dim3(capped((a.nrec + FB - 1) / FB)), dim3(FB), 0, s, a, size, shown);
+    hipLaunchKernelGGL(k_scan_partials64, dim3((uint32_t)npart), dim3(FB), 0, s, size, a.nrec, part);
+    hipLaunchKernelGGL(k_scan_top64, dim3(1), dim3(1024), 0, s, part, npart, total);
+    hipLaunchKernelGGL(k_scan_apply64, dim3((uint32_t)npart), dim3(FB), 0, s, size, a.nrec, part, pos);
+    hipLaunchKernelGGL(k_tab_write, dim3(capped((a.nrec * 16 + FB - 1) / FB)), dim3(FB), 0, s, a, pos, shown, total, out,
+                       out_capacity);
     hipLaunchKernelGGL(k_fmt_finish, dim3(1), dim3(1), 0, s, total, out_capacity, res);
     return hipGetLastError();
 }

@@ -75,6 +75,26 @@ struct FormatSeqArgs {
 
 struct FormatResult { uint64_t out_bytes; uint32_t status; uint32_t pad; };
 
+// fx2tab rows: name \t seq \t qual, then one "\t<number>" per column
+constexpr int TAB_MAX_COLS = 16, TAB_MAX_TERMS = 30, TAB_MAX_PASSES = 4;
+enum : uint8_t { TAB_LENGTH = 0, TAB_GC = 1, TAB_GC_SKEW = 2, TAB_CONTENT = 3 };
+struct TabColumn {
+    uint8_t kind;                      // TAB_*
+    uint8_t nterm;                     // TAB_CONTENT: letters summed; TAB_GC / TAB_GC_SKEW: term[0] = G, term[1] = C
+    uint8_t term[TAB_MAX_TERMS];   // pass * 8 + class of a letter's count
+};
+struct FormatTabArgs {
+    const uint8_t* text; const uint64_t* name_pos; const uint32_t* name_len;
+    const uint8_t* seq; const uint8_t* qual; const uint64_t* offsets; uint64_t nrec;
+    const uint64_t* counts[TAB_MAX_PASSES];    // per counting pass: nrec x nclass[pass]
+    uint32_t nclass[TAB_MAX_PASSES];
+    uint32_t ncols;
+    uint8_t only_id, print_seq, print_qual, pad;
+    TabColumn cols[TAB_MAX_COLS];
+};
+hipError_t launch_format_tab(const FormatTabArgs& a, uint8_t* out, uint64_t out_capacity, void* workspace,
+                             FormatResult* res, hipStream_t s);
+
 uint64_t format_workspace_size(uint64_t nrec);
 hipError_t launch_format_seq(const FormatSeqArgs& a, uint8_t* out, uint64_t out_capacity, void* workspace,
                              FormatResult* res, hipStream_t s);

@@ -372,6 +372,57 @@ int cmd_fx2tab(const GlobalOpts& g, const Fx2tabOpts& o, const std::vector<std::
         out.put('\n');
     }
 
+    // Rows built on the GPU from file text parsed on the GPU, whenever the request fits the
+    // device formatter (everything but the alphabet column and very long letter lists).
+    bool device_rows = !g.host_parse && !o.alphabet_col && npass <= SKH_TAB_MAX_PASSES;
+    skh_tab_format tf;
+    memset(&tf, 0, sizeof tf);
+    if (device_rows) {
+        auto add = [&](uint8_t kind, const std::string& list) {
+            if (tf.ncols >= SKH_TAB_MAX_COLS || list.size() > SKH_TAB_MAX_TERMS) { device_rows = false; return; }
+            skh_tab_column& c = tf.cols[tf.ncols++];
+            c.kind = kind;
+            c.nterm = (uint8_t)list.size();
+            for (size_t k = 0; k < list.size(); k++) c.term[k] = (uint8_t)letter_index((uint8_t)list[k]);
+        };
+        if (o.length) add(SKH_TAB_LENGTH, "");
+        if (o.gc) add(SKH_TAB_GC, "GC");
+        if (o.gc_skew) add(SKH_TAB_GC_SKEW, "GC");
+        for (const auto& bc : o.base) add(SKH_TAB_CONTENT, bc);
+        tf.only_id = o.only_id;
+    }
+    if (device_rows) {
+        for (const std::string& file : files) {
+            TextBlocks tb(ctx.c, file, g.text_block_bytes);
+            if (!tb.ok()) return fatal(tb.error());
+            skh_parse_result res;
+            while (tb.next(res)) {
+                skh_text* t = tb.block();
+                if (res.nrec) {
+                    {
+                        PhaseTimer pt(2);
+                        for (size_t ps = 0; ps < npass; ps++)
+                            if (skh_text_count(ctx.c, t, pass_table[ps].data(), pass_nclass[ps], (uint32_t)ps) != SKH_OK)
+                                return fatal(skh_last_error());
+                    }
+                    tf.print_seq = !o.only_name;
+                    tf.print_qual = !o.only_name && tb.is_fastq();
+                    const uint8_t* text = nullptr;
+                    uint64_t nbytes = 0;
+                    {
+                        PhaseTimer pt(3);
+                        if (skh_text_format_tab(ctx.c, t, &tf, &text, &nbytes) != SKH_OK) return fatal(skh_last_error());
+                    }
+                    PhaseTimer pt(4);
+                    out.write(text, nbytes);
+                }
+                tb.advance(res);
+            }
+            if (!tb.error().empty()) return fatal(tb.error());
+        }
+        return 0;
+    }
+
     TwoBatches tb;
     std::vector<uint64_t> cnt[2];                    // per batch: nrec x letters.size(), letter-major per record
     std::vector<uint64_t> scratch;

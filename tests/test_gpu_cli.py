@@ -87,12 +87,21 @@ FX_VARIANTS = [["-n", "-l", "-g", "-B", "AGCT"], ["-n", "-i", "-l", "-g", "-G", 
                ["-n", "-a", "-l"]]
 
 
+@pytest.mark.parametrize("mode", MODES, ids=["gpu-text", "host-parse"])
 @pytest.mark.parametrize("f", FILES)
 @pytest.mark.parametrize("flags", FX_VARIANTS, ids=lambda v: " ".join(v) or "plain")
-def test_fx2tab_matches_oracle(cli, oracle_cli, f, flags):
+def test_fx2tab_matches_oracle(cli, oracle_cli, f, flags, mode):
     want = run_cli(oracle_cli, ["fx2tab"] + flags + [f])
-    got = run_cli(cli, ["fx2tab"] + flags + [f])
+    got = run_cli(cli, ["fx2tab"] + mode + flags + [f])
     assert got[0] == want[0] == 0 and got[1] == want[1]
+
+
+def test_fx2tab_small_blocks(cli, oracle_cli):
+    for f in ("hairpin.fa.gz", "reads_1.fq.gz"):
+        flags = ["-n", "-i", "-l", "-g", "-G", "-B", "AT", "-B", "N"]
+        want = run_cli(oracle_cli, ["fx2tab"] + flags + [f])
+        got = run_cli(cli, ["fx2tab", "--batch-bytes", "5000"] + flags + [f])
+        assert got[0] == 0 and got[1] == want[1]
 
 
 def test_fx2tab_float_trap(cli):
@@ -117,7 +126,8 @@ def test_stdin_edge_cases(cli, oracle_cli):
              ">only\n", ">a\r\nAC\r\nGT\r\n>b\r\nTTTT", ">e1\n>e2\n>e3\nA\n"]
     for text in cases:
         for argv in (["seq", "-r", "-p"], ["seq", "--host-parse", "-r", "-p"],
-                     ["fx2tab", "-n", "-l", "-g", "-G", "-B", "AT"], ["stats", "-a", "-T"],
+                     ["fx2tab", "-n", "-l", "-g", "-G", "-B", "AT"], ["fx2tab", "--host-parse", "-n", "-l", "-g", "-G", "-B", "AT"],
+                     ["fx2tab", "-l", "-G"], ["stats", "-a", "-T"],
                      ["stats", "--host-parse", "-a", "-T"]):
             want = run_cli(oracle_cli, [a for a in argv if a != "--host-parse"], stdin=text)
             got = run_cli(cli, argv, stdin=text)
