@@ -34,7 +34,16 @@ namespace skh {
 namespace {
 
 constexpr int PB = 256;                      // threads per workgroup
-constexpr uint32_t TILE = PB * 16;           // text bytes per workgroup in the newline passes
+constexpr int NLU = 4;                       // 16-byte chunks per thread in the newline passes
+constexpr uint32_t TILE = PB * 16 * NLU;     // text bytes per workgroup in the newline passes
+
+// An entry of the newline index: the position of a '\n', with two facts about its
+// neighbourhood packed into the top bits while the bytes are at hand -- whether the byte
+// before it is '\r', and the first byte of the following line -- so that the line table is
+// built without touching the text again.
+constexpr uint64_t NL_POS = (1ull << 55) - 1;
+constexpr int NL_NEXT_SHIFT = 55;            // 8 bits: first byte after the newline (0 at the end of the text)
+constexpr uint64_t NL_CR = 1ull << 63;       // the line ends in "\r\n"
 constexpr int SCAN_ITEMS = 8;                // items per thread in the line scans
 constexpr uint32_t SCAN_TILE = PB * SCAN_ITEMS;
 
@@ -79,17 +88,22 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* total,
 
 // ---- pass 1: newline index ---------------------------------------------------------------
 
+__device__ __forceinline__ uint32_t nl_mask_at(const uint8_t* __restrict__ text, uint64_t n, uint64_t o)
+{
+    if (o >= n) return 0;
+    uint32_t m = nl_mask16(*reinterpret_cast<const uint4*>(text + o));
+    if (o + 16 > n) m &= (1u << (n - o)) - 1u;
+    return m;
+}
+
 __global__ __launch_bounds__(PB) void k_nl_count(const uint8_t* __restrict__ text, uint64_t n,
                                                  uint32_t* __restrict__ tile_count)
 {
     __shared__ uint32_t s_wave[PB / 64];
-    const uint64_t o = (uint64_t)blockIdx.x * TILE + threadIdx.x * 16;
     uint32_t c = 0;
-    if (o < n) {
-        uint32_t m = nl_mask16(*reinterpret_cast<const uint4*>(text + o));
-        if (o + 16 > n) m &= (1u << (n - o)) - 1u;
-        c = __builtin_popcount(m);
-    }
+#pragma unroll
+    for (int u = 0; u < NLU; u++)
+        c += __builtin_popcount(nl_mask_at(text, n, (uint64_t)blockIdx.x * TILE + (uint64_t)(u * PB + threadIdx.x) * 16));
     uint32_t total;
     block_excl_scan(c, &total, s_wave);
     if (threadIdx.x == 0) tile_count[blockIdx.x] = total;
@@ -121,20 +135,26 @@ __global__ __launch_bounds__(PB) void k_nl_scatter(const uint8_t* __restrict__ t
                                                    uint64_t* __restrict__ nlpos, uint64_t max_lines)
 {
     __shared__ uint32_t s_wave[PB / 64];
-    const uint64_t o = (uint64_t)blockIdx.x * TILE + threadIdx.x * 16;
-    uint32_t m = 0;
-    if (o < n) {
-        m = nl_mask16(*reinterpret_cast<const uint4*>(text + o));
-        if (o + 16 > n) m &= (1u << (n - o)) - 1u;
-    }
-    uint32_t total;
-    const uint32_t ex = block_excl_scan(__builtin_popcount(m), &total, s_wave);
-    uint64_t k = tile_base[blockIdx.x] + ex;
-    while (m) {
-        const uint32_t bit = __builtin_ctz(m);
-        m &= m - 1;
-        if (k < max_lines) nlpos[k] = o + bit;
-        k++;
+    uint64_t run = tile_base[blockIdx.x];
+#pragma unroll
+    for (int u = 0; u < NLU; u++) {                      // chunks in text order: u-major, then thread
+        const uint64_t o = (uint64_t)blockIdx.x * TILE + (uint64_t)(u * PB + threadIdx.x) * 16;
+        uint32_t m = nl_mask_at(text, n, o);
+        uint32_t total;
+        const uint32_t ex = block_excl_scan(__builtin_popcount(m), &total, s_wave);
+        uint64_t k = run + ex;
+        while (m) {
+            const uint32_t bit = __builtin_ctz(m);
+            m &= m - 1;
+            const uint64_t p = o + bit;
+            if (k < max_lines) {
+                const uint64_t cr = (p > 0 && text[p - 1] == '\r') ? NL_CR : 0;
+                const uint64_t next = p + 1 < n ? text[p + 1] : 0;
+                nlpos[k] = p | (next << NL_NEXT_SHIFT) | cr;
+            }
+            k++;
+        }
+        run += total;
     }
 }
 
@@ -168,14 +188,27 @@ __global__ void k_parse_init(ParseState* st, uint64_t n, int final, const uint8_
     st->total.heads = 0;
 }
 
+// Line i: its start, its length without the trailing '\r's, and its first byte (0 if empty).
 __device__ __forceinline__ void line_span(const uint8_t* __restrict__ text, uint64_t n,
                                           const uint64_t* __restrict__ nlpos, uint64_t n_nl, uint64_t i,
-                                          uint64_t& ls, uint32_t& len)
+                                          uint64_t& ls, uint32_t& len, uint8_t& first)
 {
-    ls = i ? nlpos[i - 1] + 1 : 0;
-    uint64_t le = i < n_nl ? nlpos[i] : n;
-    while (le > ls && text[le - 1] == '\r') le--;
-    len = (uint32_t)(le - ls);            // lines are shorter than 4 GiB (checked by the host side)
+    const uint64_t before = i ? nlpos[i - 1] : 0;
+    ls = i ? (before & NL_POS) + 1 : 0;
+    uint64_t le;
+    bool cr;
+    if (i < n_nl) {
+        const uint64_t e = nlpos[i];
+        le = e & NL_POS;
+        cr = (e & NL_CR) != 0;
+    } else {                                             // the unterminated last line
+        le = n;
+        cr = le > ls && text[le - 1] == '\r';
+    }
+    if (cr) { le--; while (le > ls && text[le - 1] == '\r') le--; }
+    if (le < ls) le = ls;
+    len = (uint32_t)(le - ls);            // lines are shorter than 4 GiB
+    first = len ? (i ? (uint8_t)((before >> NL_NEXT_SHIFT) & 0xff) : text[0]) : 0;
 }
 
 template <bool FASTQ>
@@ -185,35 +218,57 @@ __global__ __launch_bounds__(PB) void k_line_table(const uint8_t* __restrict__ t
                                                    uint8_t* __restrict__ line_head)
 {
     const uint64_t nlines = st->nlines, n_nl = st->n_nl;
+    // per thread, then per wavefront, then one atomic each: the flags of the whole text
+    unsigned long long err = ~0ull, blank_head = ~0ull, last = 0;
+    bool any = false;
     for (uint64_t i = (uint64_t)blockIdx.x * PB + threadIdx.x; i < nlines; i += (uint64_t)gridDim.x * PB) {
-    uint64_t ls; uint32_t len;
-    line_span(text, n, nlpos, n_nl, i, ls, len);
-    const uint8_t c = len ? text[ls] : 0;
-    bool head, bad = false;
-    if (!FASTQ) {
-        head = c == '>';
-    } else {
-        const uint32_t role = (uint32_t)(i & 3);
-        head = role == 0;
-        if (role == 0) {
-            if (len == 0) atomicMin(&st->first_blank_head, (unsigned long long)i);
-            else bad = c != '@';
-        } else if (role == 2) {
-            bad = c != '+';
-        } else if (role == 3) {
-            uint64_t ls1; uint32_t len1;
-            line_span(text, n, nlpos, n_nl, i - 2, ls1, len1);
-            bad = len1 != len;
+        uint64_t ls; uint32_t len; uint8_t c;
+        line_span(text, n, nlpos, n_nl, i, ls, len, c);
+        bool head, bad = false;
+        if (!FASTQ) {
+            head = c == '>';
+        } else {
+            const uint32_t role = (uint32_t)(i & 3);
+            head = role == 0;
+            if (role == 0) {
+                if (len == 0) blank_head = i < blank_head ? i : blank_head;
+                else bad = c != '@';
+            } else if (role == 2) {
+                bad = c != '+';
+            }                                            // role 3 (equal lengths) is checked by k_line_partials
         }
+        if (len) { last = i; any = true; }            // i grows within a thread
+        if (bad && i < err) err = i;
+        line_start[i] = ls;
+        line_len[i] = len;
+        line_head[i] = head ? 1 : 0;
     }
-    if (len) {
-        atomicMax(&st->last_nonblank, (unsigned long long)i);
-        st->any_nonblank = 1;
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned long long e2 = __shfl_xor(err, d), b2 = __shfl_xor(blank_head, d), l2 = __shfl_xor(last, d);
+        err = e2 < err ? e2 : err;
+        blank_head = b2 < blank_head ? b2 : blank_head;
+        last = l2 > last ? l2 : last;
     }
-    if (bad) atomicMin(&st->err_line, (unsigned long long)i);
-    line_start[i] = ls;
-    line_len[i] = len;
-    line_head[i] = head ? 1 : 0;
+    const bool wave_any = __any(any);
+    // same-address atomics serialise in L2: one set per workgroup, from a small grid
+    __shared__ unsigned long long s_err[PB / 64], s_blank[PB / 64], s_last[PB / 64];
+    __shared__ uint32_t s_any[PB / 64];
+    if ((threadIdx.x & 63) == 0) {
+        const uint32_t w = threadIdx.x >> 6;
+        s_err[w] = err; s_blank[w] = blank_head; s_last[w] = last; s_any[w] = wave_any ? 1u : 0u;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t a = 0;
+        for (int w = 0; w < PB / 64; w++) {
+            err = s_err[w] < err ? s_err[w] : err;
+            blank_head = s_blank[w] < blank_head ? s_blank[w] : blank_head;
+            last = s_last[w] > last ? s_last[w] : last;
+            a |= s_any[w];
+        }
+        if (err != ~0ull) atomicMin(&st->err_line, err);
+        if (blank_head != ~0ull) atomicMin(&st->first_blank_head, blank_head);
+        if (a) { atomicMax(&st->last_nonblank, last); st->any_nonblank = 1; }
     }
 }
 
@@ -235,7 +290,7 @@ __device__ __forceinline__ LineSum line_item(const uint32_t* __restrict__ line_l
 
 template <bool FASTQ>
 __global__ __launch_bounds__(PB) void k_line_partials(const uint32_t* __restrict__ line_len,
-                                                      const uint8_t* __restrict__ line_head, const ParseState* st,
+                                                      const uint8_t* __restrict__ line_head, ParseState* st,
                                                       LineSum* __restrict__ part)
 {
     __shared__ uint64_t s_b[PB / 64];
@@ -247,6 +302,9 @@ __global__ __launch_bounds__(PB) void k_line_partials(const uint32_t* __restrict
     for (int k = 0; k < SCAN_ITEMS; k++) {
         const LineSum v = line_item<FASTQ>(line_len, line_head, base + k, nlines);
         b += v.bytes; h += v.heads;
+        // FASTQ: a quality line must be as long as its sequence line (two lines up)
+        if (FASTQ && base + k < nlines && ((base + k) & 3) == 3 && line_len[base + k] != line_len[base + k - 2])
+            atomicMin(&st->err_line, (unsigned long long)(base + k));
     }
     for (int d = 1; d < 64; d <<= 1) { b += __shfl_xor(b, d); h += __shfl_xor(h, d); }
     if ((threadIdx.x & 63) == 0) { s_b[threadIdx.x >> 6] = b; s_h[threadIdx.x >> 6] = h; }
@@ -328,7 +386,7 @@ __device__ __forceinline__ uint64_t start_of_line(uint64_t k, uint64_t nlines, u
 {
     if (k < nlines) return line_start[k];
     if (nlines > n_nl) return n;                         // the last line had no newline: nothing follows
-    return nlines ? nlpos[nlines - 1] + 1 : 0;
+    return nlines ? (nlpos[nlines - 1] & NL_POS) + 1 : 0;
 }
 
 // One thread: how many complete records the block holds and where the rest starts.
@@ -524,7 +582,7 @@ static hipError_t launch_parse_t(const uint8_t* text, uint64_t n, int final, uin
     hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, tile_count, ntile, tile_base, &st->n_nl);
     hipLaunchKernelGGL(k_nl_scatter, dim3(gt), dim3(PB), 0, s, text, n, tile_base, nlpos, max_lines);
     hipLaunchKernelGGL(k_parse_init, dim3(1), dim3(1), 0, s, st, n, final, text, max_lines);
-    hipLaunchKernelGGL((k_line_table<FASTQ>), dim3(gl), dim3(PB), 0, s, text, n, nlpos, st, line_start, line_len, line_head);
+    hipLaunchKernelGGL((k_line_table<FASTQ>), dim3(gl < 2048 ? gl : 2048), dim3(PB), 0, s, text, n, nlpos, st, line_start, line_len, line_head);
     hipLaunchKernelGGL((k_line_partials<FASTQ>), dim3((uint32_t)npart), dim3(PB), 0, s, line_len, line_head, st, part);
     hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, s, part, npart, st);
     hipLaunchKernelGGL((k_line_scan<FASTQ>), dim3((uint32_t)npart), dim3(PB), 0, s, line_len, line_head, st, part, line_dst, line_rank);
