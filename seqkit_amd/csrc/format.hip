@@ -307,12 +307,24 @@ __global__ __launch_bounds__(FB) void k_tab_write(const FormatTabArgs a, const u
         if (j == 0) *o = '\t';
         o++;
         if (a.print_qual) { copy_plain<G>(o, a.qual + s, len, j); o += len; }
-        if (j == G - 1) {                       // the lane with the least copying to do
-            char buf[TAB_NUM_MAX];
-            const uint32_t nn = tab_numbers(a, r, len, buf);
-            for (uint32_t k = 0; k < nn; k++) o[k] = (uint8_t)buf[k];
-            o[nn] = '\n';
-        }
+    }
+}
+
+// the numeric columns and the line end of every row: one thread per record (all lanes busy;
+// done by one lane of a record's group the byte stores take ten times as long)
+__global__ __launch_bounds__(FB) void k_tab_numbers(const FormatTabArgs a, const uint64_t* __restrict__ pos,
+                                                    const uint32_t* __restrict__ shown_name,
+                                                    const uint64_t* __restrict__ total, uint8_t* __restrict__ out,
+                                                    uint64_t out_capacity)
+{
+    if (*total > out_capacity) return;
+    for (uint64_t r = (uint64_t)blockIdx.x * FB + threadIdx.x; r < a.nrec; r += (uint64_t)gridDim.x * FB) {
+        const uint64_t len = a.offsets[r + 1] - a.offsets[r];
+        uint8_t* o = out + pos[r] + shown_name[r] + 1 + (a.print_seq ? len : 0) + 1 + (a.print_qual ? len : 0);
+        char buf[TAB_NUM_MAX];
+        const uint32_t nn = tab_numbers(a, r, len, buf);
+        for (uint32_t k = 0; k < nn; k++) o[k] = (uint8_t)buf[k];
+        o[nn] = '\n';
     }
 }
 
@@ -370,6 +382,8 @@ hipError_t launch_format_tab(const FormatTabArgs& a, uint8_t* out, uint64_t out_
     hipLaunchKernelGGL(k_scan_top64, dim3(1), dim3(1024), 0, s, part, npart, total);
     hipLaunchKernelGGL(k_scan_apply64, dim3((uint32_t)npart), dim3(FB), 0, s, size, a.nrec, part, pos);
     hipLaunchKernelGGL(k_tab_write, dim3(capped((a.nrec * 16 + FB - 1) / FB)), dim3(FB), 0, s, a, pos, shown, total, out,
+                       out_capacity);
+    hipLaunchKernelGGL(k_tab_numbers, dim3(capped((a.nrec + FB - 1) / FB)), dim3(FB), 0, s, a, pos, shown, total, out,
                        out_capacity);
     hipLaunchKernelGGL(k_fmt_finish, dim3(1), dim3(1), 0, s, total, out_capacity, res);
     return hipGetLastError();
