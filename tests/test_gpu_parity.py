@@ -22,16 +22,29 @@ def lib():
     return load()
 
 
-@pytest.fixture(scope="module", params=["span", "groups"])
+# every reverse implementation must give the same bytes; the variables are read by skh_init
+KERNEL_SETS = {
+    "staged": {"SKH_SPAN_U": "0"},                                   # the default for short records
+    "span": {"SKH_SPAN_U": "4"},                                     # lanes own consecutive output chunks
+    "direct": {"SKH_SPAN_U": "0", "SKH_STAGED": "0"},                # lane groups without LDS staging
+    "fused": {"SKH_SPAN_U": "0", "SKH_STAGED": "0", "SKH_FUSE_FASTQ": "1"},   # bases and qualities in one launch
+    "auto": {},                                                      # kernel chosen from the mean record length
+}
+
+
+@pytest.fixture(scope="module", params=sorted(KERNEL_SETS))
 def ctx(lib, request):
-    # both reverse implementations must give the same bytes (SKH_SPAN_U is read by skh_init)
-    old = os.environ.get("SKH_SPAN_U")
-    os.environ["SKH_SPAN_U"] = "4" if request.param == "span" else "0"
+    env = KERNEL_SETS[request.param]
+    names = ("SKH_SPAN_U", "SKH_STAGED", "SKH_FUSE_FASTQ")
+    old = {k: os.environ.get(k) for k in names}
+    for k in names:
+        os.environ.pop(k, None)
+    os.environ.update(env)
     c = lib.init(0)
-    if old is None:
-        del os.environ["SKH_SPAN_U"]
-    else:
-        os.environ["SKH_SPAN_U"] = old
+    for k in names:
+        os.environ.pop(k, None)
+        if old[k] is not None:
+            os.environ[k] = old[k]
     yield c
     lib.skh_destroy(c)
 
