@@ -117,6 +117,24 @@ int skh_stats_dev(skh_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_offsets,
                   uint64_t nrec, uint64_t total_bytes, const uint8_t is_gap[256],
                   skh_stats_partial *d_out, void *stream);
 
+/* Sequence validation: seq.NewSeq's check with seq.ValidateSeq set (bio/seq; settings at
+ * seqkit/cmd/seq.go:84-93, reached through the reader at seq.go:115-127).  The first `limit`
+ * bytes of every record (all of them when limit == 0) must be members of the alphabet:
+ * valid[b] != 0.  skh_valid_table builds `valid` for an alphabet id (letters + gap +
+ * ambiguous letters; Unlimit accepts everything).  The result names the FIRST offending
+ * record of the batch and its first offending byte; the caller prints
+ * "error when parsing seq: <id> (invalid <Alphabet> letter: <c>)". */
+typedef struct skh_validate_result {
+    uint64_t record;     /* index of the first record with an invalid byte   */
+    uint64_t offset;     /* position of that byte inside the record          */
+    uint32_t letter;     /* the byte                                         */
+    uint32_t found;      /* 0: every record is valid (other fields are 0)    */
+} skh_validate_result;
+int skh_valid_table(int alphabet, uint8_t valid[256]);
+int skh_validate_dev(skh_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_offsets, uint64_t nrec,
+                     uint64_t total_bytes, const uint8_t valid[256], uint64_t limit,
+                     skh_validate_result *d_out, void *stream);
+
 /* ---- FASTA/FASTQ text -> batch on the device ----------------------------------------
  * The step before the hot path: replaces the serial record scanner behind
  * fastx.NewReader / reader.Read() (call sites seqkit/cmd/seq.go:115-127,
@@ -258,6 +276,13 @@ int skh_text_count(skh_ctx *ctx, skh_text *t, const uint8_t class_of[256], uint3
 /* skh_format_tab_dev on the block with the counts of the passes run so far + download. */
 int skh_text_format_tab(skh_ctx *ctx, skh_text *t, const skh_tab_format *fmt,
                         const uint8_t **out, uint64_t *out_bytes);
+/* skh_validate_dev on the block; *out is host memory. */
+int skh_text_validate(skh_ctx *ctx, skh_text *t, const uint8_t valid[256], uint64_t limit,
+                      skh_validate_result *out);
+/* Keeps only the first nrec records of the parsed block (e.g. those before an invalid one). */
+int skh_text_truncate(skh_ctx *ctx, skh_text *t, uint64_t nrec);
+/* Where record `record`'s name lies in the block's text buffer. */
+int skh_text_name(skh_ctx *ctx, skh_text *t, uint64_t record, uint64_t *pos, uint32_t *len);
 /* skh_stats_dev on the block, merged into *inout. */
 int skh_text_stats(skh_ctx *ctx, skh_text *t, const uint8_t is_gap[256], skh_stats_partial *inout);
 
@@ -287,6 +312,9 @@ int skh_count(skh_ctx *ctx, skh_batch *b, uint64_t nrec, const uint8_t class_of[
 void skh_stats_init(skh_stats_partial *p);
 int skh_stats_reduce(skh_ctx *ctx, skh_batch *b, uint64_t nrec, const uint8_t is_gap[256],
                      skh_stats_partial *inout);
+/* skh_validate_dev on a pinned batch; *out is host memory. */
+int skh_validate(skh_ctx *ctx, skh_batch *b, uint64_t nrec, const uint8_t valid[256], uint64_t limit,
+                 skh_validate_result *out);
 /* Merge rule for per-GPU partials (what an all-reduce applies element-wise). */
 void skh_stats_merge(skh_stats_partial *into, const skh_stats_partial *from);
 

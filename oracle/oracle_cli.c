@@ -33,7 +33,7 @@ int main(int argc, char **argv)
     const char *cmd = argv[1];
     const char *files[1024]; int nfiles = 0;
     const char *base[64]; int nbase = 0;
-    ora_seq_opts so = {0}; so.line_width = 60; so.min_len = so.max_len = -1; so.alphabet = -1; so.guess_len = 10000;
+    ora_seq_opts so = {0}; so.line_width = 60; so.min_len = so.max_len = -1; so.alphabet = -1; so.guess_len = 10000; so.validate_len = 10000;
     ora_fx2tab_opts fo = {0}; fo.guess_len = 10000;
     ora_stats_opts to = {0}; to.gap_letters = "- ."; to.guess_len = 10000;
     const char *outfile = "-";
@@ -59,6 +59,7 @@ int main(int argc, char **argv)
                         if (*p == 'r') so.reverse = 1; else if (*p == 'p') so.complement = 1;
                         else if (*p == 'n') so.only_name = 1; else if (*p == 's') so.only_seq = 1;
                         else if (*p == 'q') so.only_qual = 1; else if (*p == 'i') so.only_id = 1;
+                        else if (*p == 'v') so.validate = 1;
                         else rc = 1;
                     } else if (is_fx) {
                         if (*p == 'l') fo.length = 1; else if (*p == 'g') fo.gc = 1;
@@ -97,6 +98,8 @@ int main(int argc, char **argv)
             if (is_flag(a, "-s", "--seq")) { so.only_seq = 1; continue; }
             if (is_flag(a, "-q", "--qual")) { so.only_qual = 1; continue; }
             if (is_flag(a, "-i", "--only-id")) { so.only_id = 1; continue; }
+            if (is_flag(a, "-v", "--validate-seq")) { so.validate = 1; continue; }
+            if (is_flag(a, "-V", "--validate-seq-length")) { so.validate_len = (size_t)atoll(NEXT()); continue; }
             if (is_flag(a, "-m", "--min-len")) { so.min_len = atoi(NEXT()); continue; }
             if (is_flag(a, "-M", "--max-len")) { so.max_len = atoi(NEXT()); continue; }
         } else if (is_fx) {
@@ -119,6 +122,10 @@ int main(int argc, char **argv)
     if (nfiles == 0) files[nfiles++] = "-";   /* seqkit/cmd/helper.go:55-56 */
     fo.nbase = nbase; fo.base = base;
 
+    if (is_seq && so.alphabet >= 0 && so.alphabet != ORA_ALPHABET_Unlimit) {        /* seq.go:90-93 */
+        fprintf(stderr, "[INFO] when flag -t (--seq-type) given, flag -v (--validate-seq) is automatically switched on\n");
+        so.validate = 1;
+    }
     FILE *out = stdout;
     if (strcmp(outfile, "-") != 0 && !(out = fopen(outfile, "wb"))) { perror(outfile); return 255; }
     static char obuf[1 << 20];

@@ -41,6 +41,16 @@ void ora_alphabet_members(int a, uint8_t m[256])
     for (const char *p = ALPHA[a].ambiguous; *p; p++) m[(uint8_t)*p] = 1;
 }
 
+long ora_validate_seq(const uint8_t *seq, size_t n, int alphabet, size_t limit)
+{
+    if (alphabet < 0 || alphabet >= 6 || alphabet == ORA_ALPHABET_Unlimit) return -1;
+    uint8_t member[256];
+    ora_alphabet_members(alphabet, member);
+    if (limit != 0 && n > limit) n = limit;
+    for (size_t i = 0; i < n; i++) if (!member[seq[i]]) return (long)i;
+    return -1;
+}
+
 /* Alphabet.PairLetter: letters -> pairs, gap and ambiguous letters -> themselves.
  * A byte outside the table makes PairLetter return an error that
  * ComplementInplace ignores; the byte is left as it was (parity unpinned: no
@@ -413,6 +423,18 @@ int ora_cmd_seq(const ora_seq_opts *o, int nfiles, const char **files, FILE *out
         if (!r) { fprintf(err, "[ERRO] open %s: no such file or directory\n", files[f]); return 255; }
         ora_record rec; int rc;
         while ((rc = ora_reader_next(r, &rec)) == 1) {
+            if (o->validate) {
+                /* the reader builds every record with seq.NewSeq, which validates it: the error
+                 * ends the command before the record is filtered or printed (seq.go:120-127) */
+                const int vab = ora_reader_alphabet(r);
+                const long bad = ora_validate_seq(rec.seq, rec.seq_len, vab, o->validate_len);
+                if (bad >= 0) {
+                    fflush(out);
+                    fprintf(err, "[ERRO] error when parsing seq: %.*s (invalid %s letter: %c)\n", (int)rec.id_len,
+                            (const char *)rec.name, ora_alphabet_name(vab), rec.seq[bad]);
+                    ora_reader_close(r); free(wrapbuf); return 255;
+                }
+            }
             if (o->min_len >= 0 && rec.seq_len < (size_t)o->min_len) continue;
             if (o->max_len >= 0 && rec.seq_len > (size_t)o->max_len) continue;
             int width = ora_reader_is_fastq(r) ? 0 : o->line_width;       /* seq.go:136-138 */

@@ -109,6 +109,14 @@ int ora_reader_is_fastq(const ora_reader *r);
 int ora_reader_alphabet(const ora_reader *r);   /* -1 until the first record was read */
 void ora_reader_close(ora_reader *r);
 
+/* seq.NewSeq's check when seq.ValidateSeq is set (bio/seq, unpinned; reached through the
+ * reader at seqkit/cmd/seq.go:115-127 with the settings of seq.go:84-93): the first `limit`
+ * bytes of a record (all of them when limit == 0) must be letters, gap or ambiguous letters
+ * of the alphabet.  Returns the index of the first byte that is not, or -1.  Unlimit (and an
+ * unknown alphabet) accepts everything.  Pinned by doc/docs/usage.md:322-324 ("invalid
+ * DNAredundant letter: e") and tests/test.sh:31-32. */
+long ora_validate_seq(const uint8_t *seq, size_t n, int alphabet, size_t limit);
+
 /* ---- whole-command restatements; write exactly the bytes the Go command writes ---- */
 typedef struct ora_seq_opts {
     int reverse, complement;  /* -r -p */
@@ -117,6 +125,8 @@ typedef struct ora_seq_opts {
     int min_len, max_len;     /* -m -M (-1 = off) */
     int alphabet;             /* -t: -1 auto */
     size_t guess_len;         /* --alphabet-guess-seq-length (default 10000) */
+    int validate;             /* -v, or implied by -t (seq.go:84-93) */
+    size_t validate_len;      /* -V: bytes of each record that are checked (default 10000, 0 = all) */
 } ora_seq_opts;
 int ora_cmd_seq(const ora_seq_opts *o, int nfiles, const char **files, FILE *out, FILE *err);
 

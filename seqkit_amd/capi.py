@@ -43,6 +43,10 @@ class TabFormat(C.Structure):
 TAB_LENGTH, TAB_GC, TAB_GC_SKEW, TAB_CONTENT = 0, 1, 2, 3
 
 
+class ValidateResult(C.Structure):
+    _fields_ = [("record", C.c_uint64), ("offset", C.c_uint64), ("letter", C.c_uint32), ("found", C.c_uint32)]
+
+
 class FormatResult(C.Structure):
     _fields_ = [("out_bytes", C.c_uint64), ("status", C.c_uint32), ("reserved", C.c_uint32)]
 
@@ -73,6 +77,12 @@ SYMBOLS = {
                                      C.POINTER(TabFormat), vp, C.c_uint64, vp, C.c_uint64, vp, vp]),
     "skh_text_count": (C.c_int, [vp, vp, u8p, C.c_uint32, C.c_uint32]),
     "skh_text_format_tab": (C.c_int, [vp, vp, C.POINTER(TabFormat), C.POINTER(vp), u64p]),
+    "skh_valid_table": (C.c_int, [C.c_int, u8p]),
+    "skh_validate_dev": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_uint64, u8p, C.c_uint64, vp, vp]),
+    "skh_validate": (C.c_int, [vp, vp, C.c_uint64, u8p, C.c_uint64, C.POINTER(ValidateResult)]),
+    "skh_text_validate": (C.c_int, [vp, vp, u8p, C.c_uint64, C.POINTER(ValidateResult)]),
+    "skh_text_truncate": (C.c_int, [vp, vp, C.c_uint64]),
+    "skh_text_name": (C.c_int, [vp, vp, C.c_uint64, u64p, C.POINTER(C.c_uint32)]),
     "skh_text_alloc": (C.c_int, [vp, C.c_uint64, C.POINTER(vp)]),
     "skh_text_free": (None, [vp]),
     "skh_text_buffer": (vp, [vp]),

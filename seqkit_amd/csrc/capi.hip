@@ -202,6 +202,26 @@ int skh_pair_table(int alphabet, uint8_t lut[256])
     return SKH_OK;
 }
 
+int skh_valid_table(int alphabet, uint8_t valid[256])
+{
+    // members of an alphabet: its letters, gap letters and ambiguous letters (bio/seq alphabet.go);
+    // Unlimit accepts every byte
+    if (!valid) return fail(SKH_EINVAL, "valid is NULL");
+    const char* members = nullptr;
+    switch (alphabet) {
+        case 0: members = "acgtACGT -.nN"; break;
+        case 1: members = "acgtryswkmbdhvACGTRYSWKMBDHV -.nN"; break;
+        case 2: members = "acguACGU -.nN"; break;
+        case 3: members = "acguryswkmbdhvACGURYSWKMBDHV -.nN"; break;
+        case 4: members = "abcdefghijklmnpqrstvwyzABCDEFGHIJKLMNPQRSTVWYZ*_. -xX"; break;
+        case 5: memset(valid, 1, 256); return SKH_OK;
+        default: return fail(SKH_EINVAL, "unknown alphabet id");
+    }
+    memset(valid, 0, 256);
+    for (const char* p = members; *p; p++) valid[(uint8_t)*p] = 1;
+    return SKH_OK;
+}
+
 int skh_class_table(const char* const* lists, uint32_t nlists, uint8_t class_of[256])
 {
     if (!class_of || (nlists && !lists)) return fail(SKH_EINVAL, "NULL argument");
@@ -316,6 +336,23 @@ int skh_stats_dev(skh_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_offsets,
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
     HIP_TRY(skh::launch_stats(cfg_for(ctx, nrec, total_bytes), d_seq, d_offsets, nrec, total_bytes, t,
                               reinterpret_cast<skh::StatsPartial*>(d_out), st));
+    return SKH_OK;
+}
+
+int skh_validate_dev(skh_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_offsets, uint64_t nrec, uint64_t total_bytes,
+                     const uint8_t valid[256], uint64_t limit, skh_validate_result* d_out, void* stream)
+{
+    static_assert(sizeof(skh_validate_result) == sizeof(skh::ValidateResult), "layout");
+    if (!ctx) return fail(SKH_EINVAL, "ctx is NULL");
+    if (!valid || !d_out) return fail(SKH_EINVAL, "NULL argument");
+    int rc = check_plane_args(d_seq, d_offsets, nrec, total_bytes);
+    if (rc) return rc;
+    skh::Table256 t;
+    memcpy(t.v, valid, 256);
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    HIP_TRY(skh::launch_validate(cfg_for(ctx, nrec, total_bytes), d_seq, d_offsets, nrec, total_bytes, t, limit,
+                                 reinterpret_cast<skh::ValidateResult*>(d_out), st));
     return SKH_OK;
 }
 
@@ -627,6 +664,28 @@ int skh_stats_reduce(skh_ctx* ctx, skh_batch* b, uint64_t nrec, const uint8_t is
     return SKH_OK;
 }
 
+int skh_validate(skh_ctx* ctx, skh_batch* b, uint64_t nrec, const uint8_t valid[256], uint64_t limit,
+                 skh_validate_result* out)
+{
+    static_assert(sizeof(skh_validate_result) <= sizeof(skh::StatsPartial), "result fits the batch's result slot");
+    if (!ctx || !out) return fail(SKH_EINVAL, "NULL argument");
+    memset(out, 0, sizeof *out);
+    uint64_t total = 0;
+    int rc = batch_total(b, nrec, &total);
+    if (rc) return rc;
+    if (b->ctx != ctx) return fail(SKH_EINVAL, "batch belongs to another context");
+    if (nrec == 0) return SKH_OK;
+    rc = upload(b, nrec, total, false);
+    if (rc) return rc;
+    rc = skh_validate_dev(ctx, b->d_seq, b->d_offs, nrec, total, valid, limit,
+                          reinterpret_cast<skh_validate_result*>(b->d_stats), b->stream);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(b->h_stats, b->d_stats, sizeof(skh_validate_result), hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    memcpy(out, b->h_stats, sizeof *out);
+    return SKH_OK;
+}
+
 }  // extern "C"
 
 // ---------------------------------------------------------------- text blocks (file text in, file text out)
@@ -875,6 +934,48 @@ int skh_text_format_tab(skh_ctx* ctx, skh_text* t, const skh_tab_format* fmt, co
         hipError_t e = text_alloc_out(t, r.out_bytes + r.out_bytes / 16 + 4096);
         if (e != hipSuccess) return hip_fail(e, "growing the output buffer");
     }
+}
+
+int skh_text_validate(skh_ctx* ctx, skh_text* t, const uint8_t valid[256], uint64_t limit, skh_validate_result* out)
+{
+    if (!ctx || !t || !valid || !out) return fail(SKH_EINVAL, "NULL argument");
+    memset(out, 0, sizeof *out);
+    if (t->nrec == 0) return SKH_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc = skh_validate_dev(ctx, t->transformed ? t->d_seq2 : t->d_seq, t->d_offs, t->nrec, t->seq_bytes, valid, limit,
+                              static_cast<skh_validate_result*>(t->d_res), t->stream);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(t->h_res, t->d_res, sizeof(skh_validate_result), hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    memcpy(out, t->h_res, sizeof *out);
+    return SKH_OK;
+}
+
+int skh_text_truncate(skh_ctx* ctx, skh_text* t, uint64_t nrec)
+{
+    if (!ctx || !t) return fail(SKH_EINVAL, "NULL argument");
+    if (nrec > t->nrec) return fail(SKH_EINVAL, "cannot truncate to more records than the block holds");
+    if (nrec == t->nrec) return SKH_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpyAsync(t->h_res, t->d_offs + nrec, 8, hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    t->seq_bytes = *static_cast<uint64_t*>(t->h_res);
+    t->nrec = nrec;
+    return SKH_OK;
+}
+
+int skh_text_name(skh_ctx* ctx, skh_text* t, uint64_t record, uint64_t* pos, uint32_t* len)
+{
+    if (!ctx || !t || !pos || !len) return fail(SKH_EINVAL, "NULL argument");
+    if (record >= t->nrec) return fail(SKH_EINVAL, "record beyond the block");
+    HIP_TRY(hipSetDevice(ctx->device));
+    uint8_t* h = static_cast<uint8_t*>(t->h_res);
+    HIP_TRY(hipMemcpyAsync(h, t->d_npos + record, 8, hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(hipMemcpyAsync(h + 8, t->d_nlen + record, 4, hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    memcpy(pos, h, 8);
+    memcpy(len, h + 8, 4);
+    return SKH_OK;
 }
 
 int skh_text_stats(skh_ctx* ctx, skh_text* t, const uint8_t is_gap[256], skh_stats_partial* inout)

@@ -37,6 +37,10 @@ hipError_t launch_count(const LaunchCfg& cfg, const uint8_t* seq, const uint64_t
 hipError_t launch_stats(const LaunchCfg& cfg, const uint8_t* seq, const uint64_t* offs, uint64_t nrec,
                         uint64_t total, const Table256& is_gap, StatsPartial* out, hipStream_t st);
 
+struct ValidateResult { uint64_t record, offset; uint32_t letter, found; };   // mirrors skh_validate_result
+hipError_t launch_validate(const LaunchCfg& cfg, const uint8_t* seq, const uint64_t* offs, uint64_t nrec,
+                           uint64_t total, const Table256& valid, uint64_t limit, ValidateResult* out, hipStream_t st);
+
 // ---- text -> batch (parse.hip) ----------------------------------------------------------
 
 enum : uint32_t { PARSE_OK = 0, PARSE_EFORMAT = 1, PARSE_ECAPACITY = 2 };

@@ -1254,6 +1254,75 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_stats(const uint8_t* __restrict__
     }
 }
 
+// ------------------------------------------------------------------ validation
+//
+// seq.NewSeq's check with seq.ValidateSeq set (reached through the reader, seqkit/cmd/seq.go:
+// 84-93,115-127): the first `limit` bytes of every record (all when limit == 0) must be members
+// of the alphabet.  The answer is the first offending byte in plane order, i.e. of the first
+// offending record.  One streaming pass: sixteen table lookups per chunk; only a chunk that
+// holds a non-member byte looks up its record (binary search of the offsets).
+
+__device__ __forceinline__ uint64_t record_of(const uint64_t* __restrict__ offs, uint64_t nrec, uint64_t p)
+{
+    uint64_t lo = 0, hi = nrec;                  // last r with offs[r] <= p; p < offs[nrec]
+    while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (offs[mid] <= p) lo = mid; else hi = mid; }
+    return lo;
+}
+
+__global__ void k_validate_init(ValidateResult* out)
+{
+    out->record = ~0ull;                          // holds the first offending plane position during the scan
+    out->offset = 0; out->letter = 0; out->found = 0;
+}
+
+__global__ __launch_bounds__(SKH_BLOCK) void k_validate_scan(const uint8_t* __restrict__ seq,
+                                                             const uint64_t* __restrict__ offs, uint64_t nrec,
+                                                             uint64_t total, Table256 valid, uint64_t limit,
+                                                             ValidateResult* __restrict__ out)
+{
+    __shared__ uint8_t s_bad[256];
+    s_bad[threadIdx.x] = valid.v[threadIdx.x] ? 0 : 1;
+    __syncthreads();
+    constexpr int U = 4;
+    const uint64_t base = ((uint64_t)blockIdx.x * U * SKH_BLOCK + threadIdx.x) * 16;
+    uint4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const uint64_t o = base + (uint64_t)u * SKH_BLOCK * 16;
+        v[u] = o < total ? ld16(seq + o) : make_uint4(0, 0, 0, 0);
+    }
+    unsigned long long* first = reinterpret_cast<unsigned long long*>(&out->record);
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const uint64_t o = base + (uint64_t)u * SKH_BLOCK * 16;
+        if (o >= total) continue;
+        const uint32_t w[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+        uint32_t nbad = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) nbad += s_bad[(w[k >> 2] >> (8 * (k & 3))) & 0xffu];
+        if (nbad == 0) continue;                  // bytes past `total` are re-checked below
+        const int hi = total - o < 16 ? (int)(total - o) : 16;
+#pragma unroll 1
+        for (int k = 0; k < hi; k++) {
+            if (!s_bad[(w[k >> 2] >> (8 * (k & 3))) & 0xffu]) continue;
+            const uint64_t p = o + (uint64_t)k;
+            if (p >= *reinterpret_cast<volatile unsigned long long*>(first)) break;     // an earlier one is known
+            if (limit != 0 && p - offs[record_of(offs, nrec, p)] >= limit) continue;
+            atomicMin(first, (unsigned long long)p);
+            break;
+        }
+    }
+}
+
+__global__ void k_validate_finish(const uint8_t* __restrict__ seq, const uint64_t* __restrict__ offs, uint64_t nrec,
+                                  ValidateResult* out)
+{
+    const uint64_t p = out->record;
+    if (p == ~0ull) { out->record = 0; return; }
+    const uint64_t r = record_of(offs, nrec, p);
+    out->record = r; out->offset = p - offs[r]; out->letter = seq[p]; out->found = 1;
+}
+
 // ------------------------------------------------------------------ launchers
 
 static inline uint32_t grid_for(uint64_t work_items, uint64_t per_block, uint32_t cap)
@@ -1394,6 +1463,22 @@ hipError_t launch_stats(const LaunchCfg& cfg, const uint8_t* seq, const uint64_t
     const uint64_t items = ((total + 15) >> 4) > nrec ? ((total + 15) >> 4) : nrec;
     const uint32_t g = grid_for(items, SKH_BLOCK, resident_cap(k_stats, cfg));
     hipLaunchKernelGGL(k_stats, dim3(g), dim3(SKH_BLOCK), 0, st, seq, offs, nrec, total, is_gap, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_validate(const LaunchCfg& cfg, const uint8_t* seq, const uint64_t* offs, uint64_t nrec,
+                           uint64_t total, const Table256& valid, uint64_t limit, ValidateResult* out, hipStream_t st)
+{
+    (void)cfg;
+    hipLaunchKernelGGL(k_validate_init, dim3(1), dim3(1), 0, st, out);
+    if (nrec != 0 && total != 0) {
+        const uint64_t per_block = 4ull * SKH_BLOCK * 16;
+        const uint64_t g = (total + per_block - 1) / per_block;
+        if (g > 0x7fffffffull) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(k_validate_scan, dim3((uint32_t)g), dim3(SKH_BLOCK), 0, st, seq, offs, nrec, total, valid, limit,
+                           out);
+    }
+    hipLaunchKernelGGL(k_validate_finish, dim3(1), dim3(1), 0, st, seq, offs, nrec, out);
     return hipGetLastError();
 }
 

@@ -172,16 +172,39 @@ int seq_text_path(const GlobalOpts& g, const SeqOpts& o, const std::vector<std::
     for (const std::string& file : files) {
         TextBlocks tb(ctx, file, g.text_block_bytes);
         if (!tb.ok()) return fatal(tb.error());
-        uint8_t lut[256];
+        uint8_t lut[256], valid[256];
         bool lut_ready = false;
+        int ab = -1;                                  // the file's alphabet: -t, or guessed from its first record
+        std::string pending_error;                    // an invalid record: reported after the records before it
         skh_parse_result res;
-        while (tb.next(res)) {
+        while (pending_error.empty() && tb.next(res)) {
             skh_text* t = tb.block();
             if (res.nrec == 0) { tb.advance(res); continue; }
-            if (o.complement && !lut_ready) {
+            if (ab < 0 && (o.complement || o.validate)) {
                 std::string err;
-                const int ab = first_record_alphabet(ctx, t, g, g.alphabet, err);
+                ab = first_record_alphabet(ctx, t, g, g.alphabet, err);
                 if (ab < 0) return fatal(err);
+                skh_valid_table(ab, valid);
+            }
+            if (o.validate) {
+                // the reader validates every record it builds; the first invalid one ends the command
+                skh_validate_result vr;
+                if (skh_text_validate(ctx, t, valid, o.validate_len, &vr) != SKH_OK) return fatal(skh_last_error());
+                if (vr.found) {
+                    uint64_t npos = 0; uint32_t nlen = 0;
+                    if (skh_text_name(ctx, t, vr.record, &npos, &nlen) != SKH_OK) return fatal(skh_last_error());
+                    const uint8_t* name = skh_text_buffer(t) + npos;
+                    uint32_t idl = 0;
+                    while (idl < nlen && !(name[idl] == ' ' || (name[idl] >= '\t' && name[idl] <= '\r'))) idl++;
+                    if (idl == 0) idl = nlen;
+                    pending_error = "error when parsing seq: " + std::string((const char*)name, idl) + " (invalid " +
+                                    alphabet_name(ab) + " letter: " + std::string(1, (char)vr.letter) + ")";
+                    if (skh_text_truncate(ctx, t, vr.record) != SKH_OK) return fatal(skh_last_error());
+                    res.nrec = vr.record;
+                    if (res.nrec == 0) break;
+                }
+            }
+            if (o.complement && !lut_ready) {
                 if (!g.quiet && (ab == Protein || ab == Unlimit))
                     fprintf(stderr, "[WARN] Complement does no take effect on protein/unlimit sequence\n");
                 skh_pair_table(ab, lut);
@@ -229,8 +252,9 @@ int seq_text_path(const GlobalOpts& g, const SeqOpts& o, const std::vector<std::
                 PhaseTimer pt(4);
                 out.write(text, nbytes);
             }
-            tb.advance(res);
+            if (pending_error.empty()) tb.advance(res);
         }
+        if (!pending_error.empty()) { out.flush(); return fatal(pending_error); }
         if (!tb.error().empty()) return fatal(tb.error());
     }
     return 0;
@@ -293,10 +317,26 @@ int cmd_seq(const GlobalOpts& g, const SeqOpts& o, const std::vector<std::string
 
         int cur = 0;
         bool have_prev = false;
+        std::string pending_error;                    // an invalid record: reported after the records before it
+        uint8_t valid[256];
+        bool valid_ready = false;
         for (;;) {
             Batch& bt = tb.bt[cur];
-            const bool got = rd.next_batch(bt, g.batch_bytes, g.batch_records);
+            bool got = rd.next_batch(bt, g.batch_bytes, g.batch_records);
             if (!rd.error().empty()) return fatal("error when parsing " + file + ": " + rd.error());
+            if (got && o.validate) {
+                if (!valid_ready) { skh_valid_table(rd.alphabet(), valid); valid_ready = true; }
+                skh_validate_result vr;
+                if (skh_validate(ctx.c, bt.b, bt.nrec, valid, o.validate_len, &vr) != SKH_OK) return fatal(skh_last_error());
+                if (vr.found) {
+                    pending_error = "error when parsing seq: " +
+                                    std::string(bt.names.data() + bt.name_off[vr.record], bt.id_len[vr.record]) +
+                                    " (invalid " + alphabet_name(rd.alphabet()) + " letter: " +
+                                    std::string(1, (char)vr.letter) + ")";
+                    bt.nrec = vr.record;              // the records before it are still transformed and printed
+                    if (bt.nrec == 0) got = false;
+                }
+            }
             if (got) {
                 if (o.complement && !lut_ready) {
                     const int ab = rd.alphabet();
@@ -317,6 +357,14 @@ int cmd_seq(const GlobalOpts& g, const SeqOpts& o, const std::vector<std::string
                 Batch& pv = tb.bt[cur ^ 1];
                 if (skh_batch_wait(pv.b) != SKH_OK) return fatal(skh_last_error());
                 if (int rc = emit(pv)) return rc;
+            }
+            if (!pending_error.empty()) {
+                if (got) {
+                    if (skh_batch_wait(bt.b) != SKH_OK) return fatal(skh_last_error());
+                    if (int rc = emit(bt)) return rc;
+                }
+                out.flush();
+                return fatal(pending_error);
             }
             if (!got) break;
             have_prev = true;

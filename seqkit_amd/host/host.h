@@ -104,7 +104,9 @@ struct GlobalOpts {
                                   // and, for seq, formatted on the GPU
 };
 struct SeqOpts { bool reverse = false, complement = false, only_name = false, only_seq = false,
-                 only_qual = false, only_id = false; int min_len = -1, max_len = -1; };
+                 only_qual = false, only_id = false; int min_len = -1, max_len = -1;
+                 bool validate = false;            // -v, or implied by -t (seq.go:84-93)
+                 uint64_t validate_len = 10000; }; // -V: bytes of each record that are checked (0 = all)
 struct Fx2tabOpts { bool only_id = false, length = false, gc = false, gc_skew = false, only_name = false,
                     header_line = false, alphabet_col = false; std::vector<std::string> base; };
 struct StatsOpts { bool all = false, tabular = false; std::string gap_letters = "- ."; };

@@ -113,8 +113,9 @@ int main(int argc, char** argv)
                {nullptr, "batch-bytes", true}, {nullptr, "batch-records", true}, {nullptr, "host-parse", false}};
     if (is_seq) {
         const Flag f[] = {{"r", "reverse", false}, {"p", "complement", false}, {"n", "name", false}, {"s", "seq", false},
-                          {"q", "qual", false}, {"i", "only-id", false}, {"m", "min-len", true}, {"M", "max-len", true}};
-        p.flags.insert(p.flags.end(), f, f + 8);
+                          {"q", "qual", false}, {"i", "only-id", false}, {"m", "min-len", true}, {"M", "max-len", true},
+                          {"v", "validate-seq", false}, {"V", "validate-seq-length", true}};
+        p.flags.insert(p.flags.end(), f, f + 10);
     } else if (is_fx) {
         const Flag f[] = {{"l", "length", false}, {"g", "gc", false}, {"G", "gc-skew", false}, {"B", "base-content", true},
                           {"i", "only-id", false}, {"n", "name", false}, {"H", "header-line", false}, {"a", "alphabet", false}};
@@ -158,6 +159,15 @@ int main(int argc, char** argv)
         o.max_len = atoi(p.value("max-len", "-1").c_str());
         if (o.min_len >= 0 && o.max_len >= 0 && o.min_len > o.max_len)
             return fatal("value of flag -m (--min-len) should be >= value of flag -M (--max-len)");
+        o.validate = p.has("validate-seq");
+        const long long vl = atoll(p.value("validate-seq-length", "10000").c_str());
+        if (vl < 0) return fatal("value of flag --validate-seq-length should be greater than 0");
+        if (vl > 0 && vl < 1000) return fatal("value of flag --validate-seq-length too small, should >= 1000");   // helper.go:166-171
+        o.validate_len = (uint64_t)vl;
+        if (g.alphabet != Auto && g.alphabet != Unlimit) {                  // seq.go:90-93
+            fprintf(stderr, "[INFO] when flag -t (--seq-type) given, flag -v (--validate-seq) is automatically switched on\n");
+            o.validate = true;
+        }
         return cmd_seq(g, o, files);
     }
     if (is_fx) {

@@ -79,8 +79,11 @@ def check_vector(cli, name, vec):
     with open(os.path.join(GOLDEN, "expected", name + ".txt"), "rb") as fh:
         want = fh.read()
     rc, got, err = run_cli(cli, vec["argv"], vec.get("stdin"))
-    assert rc == 0, err.decode()
     mode = vec["mode"]
+    if mode == "stderr255":
+        assert rc == 255 and got == b"" and err == want
+        return
+    assert rc == 0, err.decode()
     if mode == "exact":
         assert got == want
     elif mode == "head3":

@@ -52,6 +52,9 @@ VECTORS = {
         ["stats"], "exact", "stdin: @read\\nACTGCN\\n+\\n@IICCG"),
     "G9_seq_illumina15": ("doc/docs/usage.md", 944, 947, 0,
         ["seq", "Illimina1.5.fq"], "exact", "FASTQ round trip, '+' line reduced to '+'"),
+    "G10_seq_validate": ("doc/docs/usage.md", 323, 324, 12,
+        ["seq", "-t", "dna"], "stderr255",
+        "sequence validation switched on by -t: both stderr lines, nothing on stdout, exit status 255"),
 }
 
 STDIN = {
@@ -59,6 +62,7 @@ STDIN = {
     "G4_stats_rna": ">seq\nACGUN ACGUN\n",
     "G4_stats_protein": ">seq\nabcdefghijklmnpqrstvwyz\n",
     "G4_stats_fastq": "@read\nACTGCN\n+\n@IICCG\n",
+    "G10_seq_validate": ">seq\nabcdefghijklmnpqrstvwyz\n",
 }
 
 

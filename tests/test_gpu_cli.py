@@ -59,6 +59,31 @@ def test_seq_selection_flags_gpu_text(cli, oracle_cli, flags):
         assert got[0] == want[0] == 0 and got[1] == want[1], (f, flags)
 
 
+@pytest.mark.parametrize("mode", MODES, ids=["gpu-text", "host-parse"])
+def test_seq_validation(cli, oracle_cli, mode, tmp_path):
+    # tests/test.sh:31-32 of the reference: RNA hairpins are not DNA
+    rc, out, err = run_cli(cli, ["seq"] + mode + ["-t", "dna", "hairpin.fa.gz"])
+    assert rc == 255 and out == b"" and b"invalid DNAredundant letter" in err
+    # an invalid record in the middle: the records before it are printed, then the error
+    p = tmp_path / "mid.fa"
+    recs = [">r%d d\n%s\n" % (i, "ACGTN" * (5 + i % 7)) for i in range(500)]
+    recs[321] = ">bad one\nACGTACGTeACGT\n"
+    p.write_text("".join(recs))
+    for extra in ([], ["--batch-bytes", "4096", "--batch-records", "64"], ["-r", "-p"]):
+        flags = ["-v"] + [a for a in extra if a in ("-r", "-p")]
+        want = run_cli(oracle_cli, ["seq"] + flags + [str(p)])
+        got = run_cli(cli, ["seq"] + mode + ["-v"] + extra + [str(p)])
+        assert want[0] == 255 and got[0] == 255 and got[1] == want[1]
+        assert got[2].splitlines()[-1] == want[2].splitlines()[-1] == b"[ERRO] error when parsing seq: bad (invalid DNAredundant letter: e)"
+    # beyond the validated prefix nothing is looked at; -V 0 looks at everything
+    q = tmp_path / "far.fa"
+    q.write_text(">long\n" + "A" * 12000 + "e" + "\n")
+    assert run_cli(cli, ["seq"] + mode + ["-v", str(q)])[0] == 0
+    assert run_cli(cli, ["seq"] + mode + ["-v", "-V", "0", str(q)])[0] == 255
+    want = run_cli(oracle_cli, ["seq", "-v", "-V", "0", str(q)])
+    assert want[0] == 255
+
+
 def test_seq_multiline_fastq(cli, oracle_cli):
     text = "@r1\nACGT\nAC\n+\nIIII\nII\n"
     rc, _, err = run_cli(cli, ["seq"], stdin=text)

@@ -18,6 +18,7 @@ counts = torch.empty(nrec * 8, dtype=torch.int64, device=dev)
 stats = torch.zeros(5, dtype=torch.int64, device=dev)
 lut = lib.pair_table(1); cls4 = lib.class_table(["G", "C", "A", "T"]); cls6 = lib.class_table(["G", "C", "A", "T", "N", "-"])
 gap = (C.c_uint8 * 256)(); gap[ord("-")] = 1
+valid = (C.c_uint8 * 256)(); lib.check(lib.skh_valid_table(1, valid))
 torch.cuda.synchronize()   # data was generated on the default stream
 st = torch.cuda.Stream(device=dev); sp = C.c_void_p(st.cuda_stream)
 p = lambda t: C.c_void_p(t.data_ptr())
@@ -30,6 +31,7 @@ cases = {
     "complement only (aligned, 2B/base)": (lambda: lib.skh_revcomp_dev(ctx, p(seq), p(so), p(offs), nrec, total, lut, 0, sp), 2 * total),
     "count 4 classes (1B/base+40B/rec)": (lambda: lib.skh_count_dev(ctx, p(seq), p(offs), nrec, total, cls4, 4, p(counts), sp), total + 40 * nrec),
     "count 6 classes (1B/base+56B/rec)": (lambda: lib.skh_count_dev(ctx, p(seq), p(offs), nrec, total, cls6, 6, p(counts), sp), total + 56 * nrec),
+    "validate DNAredundant, all bytes (1B/base)": (lambda: lib.skh_validate_dev(ctx, p(seq), p(offs), nrec, total, valid, 0, p(stats), sp), total),
     "stats (1B/base+8B/rec)": (lambda: lib.skh_stats_dev(ctx, p(seq), p(offs), nrec, total, gap, p(stats), sp), total + 8 * nrec),
 }
 with torch.cuda.stream(st):
