@@ -61,6 +61,7 @@ struct skh_ctx {
     int staged = 1;
     uint32_t staged_steps = 0;
     uint32_t count_steps = 0;
+    uint32_t stats_steps = 0;
 };
 
 struct skh_batch {
@@ -94,6 +95,7 @@ skh::LaunchCfg cfg_for(const skh_ctx* ctx, uint64_t nrec, uint64_t total)
     c.staged = ctx->staged;
     c.staged_steps = ctx->staged_steps;
     c.count_steps = ctx->count_steps;
+    c.stats_steps = ctx->stats_steps;
     if (ctx->force_logG >= 0) {
         c.logG = ctx->force_logG > 6 ? 6 : ctx->force_logG;
         return c;
@@ -152,6 +154,7 @@ int skh_init(int device, skh_ctx** out)
     c->staged = env_int("SKH_STAGED", 1);
     c->staged_steps = (uint32_t)env_int("SKH_STAGED_STEPS", 0);
     c->count_steps = (uint32_t)env_int("SKH_COUNT_STEPS", 0);
+    c->stats_steps = (uint32_t)env_int("SKH_STATS_STEPS", 0);
     e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->d_flags), N_FLAGS * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemset(c->d_flags, 0, N_FLAGS * sizeof(uint32_t));

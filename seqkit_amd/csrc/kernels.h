@@ -20,6 +20,7 @@ struct LaunchCfg {
     int staged;          // reverse, short records: 1 = LDS-staged kernel, 0 = direct (lane exchange) kernel
     uint32_t staged_steps;   // staged kernel: steps per wavefront (0 = default)
     uint32_t count_steps;    // short count kernel: steps per wavefront (0 = default)
+    uint32_t stats_steps;    // stats kernel: runs of chunks per workgroup (0 = default)
     int fuse_fastq;      // reverse: 1 = bases and qualities in one launch, 0 = one launch per plane
     int span_u;          // reverse: 0 = lane-group kernels, 2 or 4 = span kernel with that many chunks per lane
 };

@@ -1195,10 +1195,14 @@ __global__ void k_stats_init(StatsPartial* out, uint64_t nrec, uint64_t total)
 }
 
 // gap_sum over the whole plane (record boundaries are irrelevant to a file total)
-// and min/max of the record lengths from the offsets, in one grid.
+// and min/max of the record lengths from the offsets, in one grid that covers the plane once, in
+// address order: workgroup b reads `steps` runs of STATS_U * SKH_BLOCK consecutive chunks (the loads of a run
+// issued before its first table lookup) and its share `rpb` of the records, then reduces once.
+constexpr int STATS_U = 4;
+
 __global__ __launch_bounds__(SKH_BLOCK) void k_stats(const uint8_t* __restrict__ seq,
                                                      const uint64_t* __restrict__ offs, uint64_t nrec,
-                                                     uint64_t total, Table256 is_gap,
+                                                     uint64_t total, uint64_t rpb, uint32_t steps, Table256 is_gap,
                                                      StatsPartial* __restrict__ out)
 {
     __shared__ uint8_t s_gap[256];
@@ -1206,29 +1210,36 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_stats(const uint8_t* __restrict__
     __shared__ long long s_min[SKH_BLOCK / 64], s_max[SKH_BLOCK / 64];
     s_gap[threadIdx.x] = is_gap.v[threadIdx.x] ? 1 : 0;
     __syncthreads();
-    const uint64_t stride = (uint64_t)gridDim.x * SKH_BLOCK;
-    const uint64_t gid = (uint64_t)blockIdx.x * SKH_BLOCK + threadIdx.x;
-
-    unsigned long long gaps = 0;
-    const uint64_t nchunk = (total + 15) >> 4;
-    for (uint64_t c = gid; c < nchunk; c += stride) {
-        const uint64_t o = c << 4;
-        const uint4 v = ld16(seq + o);
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-        uint32_t n = 0;
-        if (o + 16 <= total) {
+    uint32_t n = 0;
+    for (uint32_t it = 0; it < steps; it++) {
+        const uint64_t base = (((uint64_t)blockIdx.x * steps + it) * STATS_U * SKH_BLOCK + threadIdx.x) * 16;
+        if (base >= total) break;
+        uint4 v[STATS_U];
 #pragma unroll
-            for (int k = 0; k < 16; k++) n += s_gap[(w[k >> 2] >> (8 * (k & 3))) & 0xffu];
-        } else {
-            const int hi = (int)(total - o);
-#pragma unroll
-            for (int k = 0; k < 16; k++)
-                if (k < hi) n += s_gap[(w[k >> 2] >> (8 * (k & 3))) & 0xffu];
+        for (int u = 0; u < STATS_U; u++) {
+            const uint64_t o = base + (uint64_t)u * SKH_BLOCK * 16;
+            v[u] = o < total ? ld16(seq + o) : make_uint4(0, 0, 0, 0);
         }
-        gaps += n;
+#pragma unroll
+        for (int u = 0; u < STATS_U; u++) {
+            const uint64_t o = base + (uint64_t)u * SKH_BLOCK * 16;
+            const uint32_t w[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+            if (o + 16 <= total) {
+#pragma unroll
+                for (int k = 0; k < 16; k++) n += s_gap[(w[k >> 2] >> (8 * (k & 3))) & 0xffu];
+            } else if (o < total) {
+                const int hi = (int)(total - o);
+#pragma unroll
+                for (int k = 0; k < 16; k++)
+                    if (k < hi) n += s_gap[(w[k >> 2] >> (8 * (k & 3))) & 0xffu];
+            }
+        }
     }
+    unsigned long long gaps = n;
     long long lmin = INT64_MAX, lmax = 0;
-    for (uint64_t r = gid; r < nrec; r += stride) {
+    const uint64_t r0 = (uint64_t)blockIdx.x * rpb;
+    const uint64_t r1 = r0 + rpb < nrec ? r0 + rpb : nrec;
+    for (uint64_t r = r0 + threadIdx.x; r < r1; r += SKH_BLOCK) {
         const long long len = (long long)(offs[r + 1] - offs[r]);
         lmin = len < lmin ? len : lmin;
         lmax = len > lmax ? len : lmax;
@@ -1248,9 +1259,13 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_stats(const uint8_t* __restrict__
             lmin = s_min[w] < lmin ? s_min[w] : lmin;
             lmax = s_max[w] > lmax ? s_max[w] : lmax;
         }
+        // the grid is large: only a workgroup that improves on the totals so far touches them
+        // (atomics on one address are served one after the other)
         if (gaps) atomicAdd(reinterpret_cast<unsigned long long*>(&out->gap_sum), gaps);
-        if (lmin != INT64_MAX) atomicMin(reinterpret_cast<long long*>(&out->len_min), lmin);
-        if (lmax != 0) atomicMax(reinterpret_cast<long long*>(&out->len_max), lmax);
+        if (lmin < *reinterpret_cast<volatile long long*>(&out->len_min))
+            atomicMin(reinterpret_cast<long long*>(&out->len_min), lmin);
+        if (lmax > *reinterpret_cast<volatile long long*>(&out->len_max))
+            atomicMax(reinterpret_cast<long long*>(&out->len_max), lmax);
     }
 }
 
@@ -1460,9 +1475,15 @@ hipError_t launch_stats(const LaunchCfg& cfg, const uint8_t* seq, const uint64_t
                         uint64_t total, const Table256& is_gap, StatsPartial* out, hipStream_t st)
 {
     hipLaunchKernelGGL(k_stats_init, dim3(1), dim3(1), 0, st, out, nrec, total);
-    const uint64_t items = ((total + 15) >> 4) > nrec ? ((total + 15) >> 4) : nrec;
-    const uint32_t g = grid_for(items, SKH_BLOCK, resident_cap(k_stats, cfg));
-    hipLaunchKernelGGL(k_stats, dim3(g), dim3(SKH_BLOCK), 0, st, seq, offs, nrec, total, is_gap, out);
+    const uint32_t steps = cfg.stats_steps > 0 ? (uint32_t)cfg.stats_steps : 4u;
+    const uint64_t per_block = (uint64_t)STATS_U * SKH_BLOCK * steps;
+    uint64_t g = (((total + 15) >> 4) + per_block - 1) / per_block;
+    const uint64_t g_rec = (nrec + 16ull * SKH_BLOCK - 1) / (16ull * SKH_BLOCK);
+    if (g < g_rec) g = g_rec;
+    if (g < 1) g = 1;
+    if (g > 0x7fffffffull) return hipErrorInvalidValue;
+    const uint64_t rpb = (nrec + g - 1) / g;
+    hipLaunchKernelGGL(k_stats, dim3((uint32_t)g), dim3(SKH_BLOCK), 0, st, seq, offs, nrec, total, rpb, steps, is_gap, out);
     return hipGetLastError();
 }
 
