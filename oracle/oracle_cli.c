@@ -1,9 +1,10 @@
 /*
  * oracle_cli.c -- TEST INFRASTRUCTURE ONLY (see seqkit_oracle.h).
  *
- * `seqkit_oracle seq|fx2tab|stats [flags] [files...]`: the three reference commands
+ * `seqkit_oracle seq|fx2tab|stats|subseq [flags] [files...]`: the reference commands
  * on the CPU restatement, with the reference's flag letters
- * (seqkit/cmd/seq.go:291-306, fx2tab.go:157-164, stat.go:292-294, root.go:65-72).
+ * (seqkit/cmd/seq.go:291-306, fx2tab.go:157-164, stat.go:292-294, subseq.go:549-564,
+ * root.go:65-72).
  * Used by the tests to produce expected bytes and by bench.py as the timed CPU
  * baseline; never by the product.
  */
@@ -15,7 +16,7 @@
 
 static int usage(void)
 {
-    fprintf(stderr, "usage: seqkit_oracle seq|fx2tab|stats [flags] [files...]\n");
+    fprintf(stderr, "usage: seqkit_oracle seq|fx2tab|stats|subseq [flags] [files...]\n");
     return 255;
 }
 
@@ -36,16 +37,18 @@ int main(int argc, char **argv)
     ora_seq_opts so = {0}; so.line_width = 60; so.min_len = so.max_len = -1; so.alphabet = -1; so.guess_len = 10000; so.validate_len = 10000;
     ora_fx2tab_opts fo = {0}; fo.guess_len = 10000;
     ora_stats_opts to = {0}; to.gap_letters = "- ."; to.guess_len = 10000;
+    ora_subseq_opts uo = {0}; uo.gtf_tag = "gene_id"; uo.guess_len = 10000;
+    static const char *chrs[256], *feats[256];
     const char *outfile = "-";
     int is_seq = !strcmp(cmd, "seq"), is_fx = !strcmp(cmd, "fx2tab"),
-        is_st = !strcmp(cmd, "stats") || !strcmp(cmd, "stat");
-    if (!is_seq && !is_fx && !is_st) return usage();
+        is_st = !strcmp(cmd, "stats") || !strcmp(cmd, "stat"), is_sub = !strcmp(cmd, "subseq");
+    if (!is_seq && !is_fx && !is_st && !is_sub) return usage();
 
     for (int i = 2; i < argc; i++) {
         const char *a = argv[i];
         if (a[0] != '-' || !strcmp(a, "-")) { if (nfiles < 1024) files[nfiles++] = a; continue; }
         /* bundled short bool flags, e.g. -rp or -nlg */
-        if (a[1] != '-' && strlen(a) > 2) {
+        if (!is_sub && a[1] != '-' && strlen(a) > 2) {
             int all_bool = 1;
             for (const char *p = a + 1; *p; p++) if (!strchr("rpnsqilgGHaT", *p)) all_bool = 0;
             if (all_bool && !(is_st && strchr(a, 'G')) && !(is_seq && strchr(a, 'G'))) {
@@ -80,7 +83,7 @@ int main(int argc, char **argv)
         if (is_flag(a, "-j", "--threads")) { (void)NEXT(); continue; }
         if (is_flag(a, NULL, "--quiet")) continue;
         if (is_flag(a, NULL, "--alphabet-guess-seq-length")) {
-            size_t v = (size_t)atoll(NEXT()); so.guess_len = fo.guess_len = to.guess_len = v; continue;
+            size_t v = (size_t)atoll(NEXT()); so.guess_len = fo.guess_len = to.guess_len = uo.guess_len = v; continue;
         }
         if (is_flag(a, "-t", "--seq-type")) {
             const char *v = NEXT();
@@ -102,6 +105,23 @@ int main(int argc, char **argv)
             if (is_flag(a, "-V", "--validate-seq-length")) { so.validate_len = (size_t)atoll(NEXT()); continue; }
             if (is_flag(a, "-m", "--min-len")) { so.min_len = atoi(NEXT()); continue; }
             if (is_flag(a, "-M", "--max-len")) { so.max_len = atoi(NEXT()); continue; }
+        } else if (is_sub) {
+            if (is_flag(a, "-r", "--region")) { uo.region = NEXT(); continue; }
+            if (is_flag(a, NULL, "--gtf")) { uo.gtf = NEXT(); continue; }
+            if (is_flag(a, NULL, "--bed")) { uo.bed = NEXT(); continue; }
+            if (is_flag(a, NULL, "--gtf-tag")) { uo.gtf_tag = NEXT(); continue; }
+            if (is_flag(a, "-u", "--up-stream")) { uo.up_stream = atoi(NEXT()); continue; }
+            if (is_flag(a, "-d", "--down-stream")) { uo.down_stream = atoi(NEXT()); continue; }
+            if (is_flag(a, "-f", "--only-flank")) { uo.only_flank = 1; continue; }
+            if (is_flag(a, NULL, "--chr") || is_flag(a, NULL, "--feature")) {      /* comma-separated, repeatable */
+                const int is_chr = a[2] == 'c';
+                char *v = strdup(NEXT());
+                for (char *tok = strtok(v, ","); tok; tok = strtok(NULL, ",")) {
+                    if (is_chr) { if (uo.nchr < 256) chrs[uo.nchr++] = tok; }
+                    else if (uo.nfeature < 256) feats[uo.nfeature++] = tok;
+                }
+                continue;
+            }
         } else if (is_fx) {
             if (is_flag(a, "-l", "--length")) { fo.length = 1; continue; }
             if (is_flag(a, "-g", "--gc")) { fo.gc = 1; continue; }
@@ -121,6 +141,7 @@ int main(int argc, char **argv)
     }
     if (nfiles == 0) files[nfiles++] = "-";   /* seqkit/cmd/helper.go:55-56 */
     fo.nbase = nbase; fo.base = base;
+    uo.chr = chrs; uo.feature = feats; uo.line_width = so.line_width;
 
     if (is_seq && so.alphabet >= 0 && so.alphabet != ORA_ALPHABET_Unlimit) {        /* seq.go:90-93 */
         fprintf(stderr, "[INFO] when flag -t (--seq-type) given, flag -v (--validate-seq) is automatically switched on\n");
@@ -132,6 +153,7 @@ int main(int argc, char **argv)
     setvbuf(out, obuf, _IOFBF, sizeof obuf);
     int rc = is_seq ? ora_cmd_seq(&so, nfiles, files, out, stderr)
            : is_fx  ? ora_cmd_fx2tab(&fo, nfiles, files, out, stderr)
+           : is_sub ? ora_cmd_subseq(&uo, nfiles, files, out, stderr)
                     : ora_cmd_stats(&to, nfiles, files, out, stderr);
     if (out != stdout) fclose(out); else fflush(out);
     return rc;

@@ -9,9 +9,11 @@
  */
 #include "seqkit_oracle.h"
 
+#include <ctype.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <strings.h>
 #include <zlib.h>
 
 /* ------------------------------------------------------------------ alphabets */
@@ -651,4 +653,312 @@ int ora_cmd_stats(const ora_stats_opts *o, int nfiles, const char **files, FILE 
     for (int r = 0; r < nrow; r++) { for (int c = 0; c < ncol; c++) free(cells[r][c]); free(cells[r]); }
     free(cells); free(infos);
     return 0;
+}
+
+/* ------------------------------------------------------------------ subseq */
+int ora_sub_location(int64_t length, int64_t start, int64_t end, int64_t *s, int64_t *e)
+{
+    *s = 0; *e = 0;
+    if (length == 0) return 0;
+    if (start < 1) {
+        if (start == 0) start = 1;
+        else {
+            if (end < 0 && start > end) return 0;
+            start = -start > length ? 1 : length + start + 1;
+        }
+    }
+    if (start > length) return 0;
+    if (end > length) end = length;
+    if (end < 1) {
+        if (end == 0) end = -1;
+        end = length + end + 1;
+    }
+    if (start - 1 > end) return 0;
+    *s = start; *e = end;
+    return 1;
+}
+
+void ora_batch_subseq(const uint8_t *seq, const uint8_t *qual, const uint64_t *offs, uint64_t nrec,
+                      const ora_slice *slices, uint64_t n, const uint8_t *lut,
+                      uint8_t *out_seq, uint8_t *out_qual, uint64_t *out_offs)
+{
+    uint64_t w = 0;
+    (void)nrec;
+    for (uint64_t i = 0; i < n; i++) {
+        const uint64_t a = offs[slices[i].record], len = offs[slices[i].record + 1] - a;
+        int64_t s, e;
+        out_offs[i] = w;
+        if (!ora_sub_location((int64_t)len, slices[i].start, slices[i].end, &s, &e)) continue;
+        const uint64_t m = e >= s ? (uint64_t)(e - s + 1) : 0;
+        memcpy(out_seq + w, seq + a + (uint64_t)(s - 1), m);
+        if (qual) memcpy(out_qual + w, qual + a + (uint64_t)(s - 1), m);
+        if (slices[i].minus) {                       /* RevComInplace = ReverseInplace + ComplementInplace */
+            ora_reverse_inplace(out_seq + w, qual ? out_qual + w : NULL, m);
+            if (lut) for (uint64_t k = 0; k < m; k++) out_seq[w + k] = lut[out_seq[w + k]];
+        }
+        w += m;
+    }
+    out_offs[n] = w;
+}
+
+typedef struct feature {
+    char *chr, *type, *label;     /* label: value of the chosen GTF tag / BED name ("" if absent) */
+    int64_t start, end;           /* 1-based, inclusive */
+    char strand;                  /* '+', '-', or 0 = not given */
+} feature;
+
+static char *dup_lower(const char *s, size_t n)
+{
+    char *d = (char *)malloc(n + 1);
+    for (size_t i = 0; i < n; i++) d[i] = (char)tolower((unsigned char)s[i]);
+    d[n] = 0;
+    return d;
+}
+
+static char *dup_n(const char *s, size_t n)
+{
+    char *d = (char *)malloc(n + 1);
+    memcpy(d, s, n); d[n] = 0;
+    return d;
+}
+
+static int in_list_ci(const char *v, int n, const char **list)
+{
+    for (int i = 0; i < n; i++) if (strcasecmp(v, list[i]) == 0) return 1;
+    return 0;
+}
+
+static int split_tabs(char *line, char **items, int max)
+{
+    int n = 0;
+    char *p = line;
+    while (n < max) {
+        items[n++] = p;
+        char *t = strchr(p, '\t');
+        if (!t) break;
+        *t = 0; p = t + 1;
+    }
+    return n;
+}
+
+/* value of `tag` in a GTF attribute column: `tag "value"; tag2 "value2";` */
+static char *gtf_tag_value(const char *attrs, const char *tag)
+{
+    const size_t tl = strlen(tag);
+    const char *p = attrs;
+    while (*p) {
+        while (*p == ' ' || *p == ';') p++;
+        const char *q = p;
+        while (*q && *q != ';') {
+            if (*q == '"') { q++; while (*q && *q != '"') q++; if (*q) q++; } else q++;
+        }
+        if ((size_t)(q - p) > tl && strncmp(p, tag, tl) == 0 && p[tl] == ' ') {
+            const char *v = p + tl + 1, *ve = q;
+            while (ve > v && ve[-1] == ' ') ve--;
+            if (ve - v >= 2 && v[0] == '"' && ve[-1] == '"') { v++; ve--; }
+            return dup_n(v, (size_t)(ve - v));
+        }
+        p = q;
+    }
+    return dup_n("", 0);
+}
+
+/* bio/featio/gtf ReadFilteredFeatures (unpinned) and cmd/bed.go:52-121.  Returns -1 on error. */
+static long read_features(const ora_subseq_opts *o, int is_bed, feature **out, FILE *err)
+{
+    const char *path = is_bed ? o->bed : o->gtf;
+    gzFile fh = gzopen(path, "rb");
+    if (!fh) { fprintf(err, "[ERRO] open %s: no such file or directory\n", path); return -1; }
+    size_t cap = 1 << 16, nf = 0, fcap = 64;
+    char *line = (char *)malloc(cap);
+    feature *fs = (feature *)malloc(fcap * sizeof *fs);
+    for (;;) {
+        size_t n = 0;
+        int c = 0, any = 0;
+        while ((c = gzgetc(fh)) != -1) {
+            any = 1;
+            if (c == '\n') break;
+            if (n + 2 > cap) { cap *= 2; line = (char *)realloc(line, cap); }
+            line[n++] = (char)c;
+        }
+        if (!any) break;
+        while (n && (line[n - 1] == '\r' || line[n - 1] == '\n')) n--;
+        line[n] = 0;
+        if (n == 0 || line[0] == '#') continue;
+        char *it[16];
+        feature f; memset(&f, 0, sizeof f);
+        if (is_bed) {
+            if ((n > 7 && strncmp(line, "browser", 7) == 0) || (n > 5 && strncmp(line, "track", 5) == 0)) continue;
+            int k = split_tabs(line, it, 16);
+            if (k < 3) continue;
+            if (o->nchr > 0) {                                 /* bed.go:75-79: exact match */
+                int hit = 0;
+                for (int i = 0; i < o->nchr; i++) if (strcmp(it[0], o->chr[i]) == 0) hit = 1;
+                if (!hit) continue;
+            }
+            char *e1, *e2;
+            long long a = strtoll(it[1], &e1, 10), b = strtoll(it[2], &e2, 10);
+            if (*e1 || e1 == it[1]) { fprintf(err, "[ERRO] %s: bad start: %s\n", it[0], it[1]); goto fail; }
+            if (*e2 || e2 == it[2]) { fprintf(err, "[ERRO] %s: bad end: %s\n", it[0], it[2]); goto fail; }
+            if (a >= b) { fprintf(err, "[ERRO] %s: start (%lld) must be <= end (%lld)\n", it[0], a, b); goto fail; }
+            if (k >= 6 && strcmp(it[5], "+") != 0 && strcmp(it[5], "-") != 0) {
+                fprintf(err, "[ERRO] bad strand: %s\n", it[5]); goto fail;
+            }
+            f.chr = dup_n(it[0], strlen(it[0])); f.type = dup_n("", 0);
+            f.label = k >= 4 ? dup_n(it[3], strlen(it[3])) : dup_n("", 0);
+            f.start = a + 1; f.end = b; f.strand = k >= 6 ? it[5][0] : 0;
+        } else {
+            int k = split_tabs(line, it, 9);
+            if (k < 9) continue;
+            if (o->nchr > 0 && !in_list_ci(it[0], o->nchr, o->chr)) continue;
+            if (o->nfeature > 0 && !in_list_ci(it[2], o->nfeature, o->feature)) continue;
+            f.chr = dup_n(it[0], strlen(it[0])); f.type = dup_lower(it[2], strlen(it[2]));
+            f.start = atoll(it[3]); f.end = atoll(it[4]);
+            f.strand = (it[6][0] == '+' || it[6][0] == '-') ? it[6][0] : 0;
+            f.label = gtf_tag_value(it[8], o->gtf_tag);
+        }
+        if (nf == fcap) { fcap *= 2; fs = (feature *)realloc(fs, fcap * sizeof *fs); }
+        fs[nf++] = f;
+    }
+    gzclose(fh); free(line);
+    *out = fs;
+    return (long)nf;
+fail:
+    gzclose(fh); free(line); free(fs);
+    return -1;
+}
+
+static void write_fasta(FILE *out, const char *name, size_t name_len, const uint8_t *seq, size_t n, int width,
+                        uint8_t **wrapbuf, size_t *wrapcap)
+{
+    size_t need = n + (width > 0 ? n / (size_t)width : 0) + 1;
+    if (need > *wrapcap) { *wrapbuf = (uint8_t *)realloc(*wrapbuf, need); *wrapcap = need; }
+    fputc('>', out); fwrite(name, 1, name_len, out); fputc('\n', out);
+    size_t m = ora_wrap(seq, n, width, *wrapbuf);
+    fwrite(*wrapbuf, 1, m, out); fputc('\n', out);
+}
+
+int ora_cmd_subseq(const ora_subseq_opts *o, int nfiles, const char **files, FILE *out, FILE *err)
+{
+    int64_t start = 0, end = 0;
+    const int by_region = o->region && o->region[0];
+    const int by_gtf = !by_region && o->gtf && o->gtf[0];
+    const int by_bed = !by_region && !by_gtf && o->bed && o->bed[0];
+    if (o->only_flank) {                                                         /* subseq.go:94-102 */
+        if (o->up_stream > 0 && o->down_stream > 0) {
+            fprintf(err, "[ERRO] when flag -f (--only-flank) given, only one of flags -u (--up-stream) and -d (--down-stream) is allowed\n");
+            return 255;
+        }
+        if (o->up_stream == 0 && o->down_stream == 0) {
+            fprintf(err, "[ERRO] when flag -f (--only-flank) given, one of flags -u (--up-stream) and -d (--down-stream) should be given\n");
+            return 255;
+        }
+    }
+    if (by_region) {                                                             /* subseq.go:103-138 */
+        if (o->up_stream > 0 || o->down_stream > 0 || o->only_flank) {
+            fprintf(err, "[ERRO] when flag -r (--region) given, any of flags -u (--up-stream), -d (--down-stream) and -f (--only-flank) is not allowed\n");
+            return 255;
+        }
+        char *e1 = NULL, *e2 = NULL;
+        long long a = strtoll(o->region, &e1, 10), b = 0;
+        int ok = e1 != o->region && *e1 == ':';
+        if (ok) { b = strtoll(e1 + 1, &e2, 10); ok = e2 != e1 + 1 && *e2 == 0; }
+        if (!ok) {
+            fprintf(err, "[ERRO] invalid region: %s. type \"seqkit subseq -h\" for more examples\n", o->region);
+            return 255;
+        }
+        if (a == 0 || b == 0) { fprintf(err, "[ERRO] both start and end should not be 0\n"); return 255; }
+        if (a < 0 && b > 0) { fprintf(err, "[ERRO] when start < 0, end should not > 0\n"); return 255; }
+        start = a; end = b;
+    }
+    feature *fs = NULL; long nf = 0;
+    char **types = NULL; long ntypes = 0;
+    if (by_gtf || by_bed) {
+        if (by_bed && o->nfeature > 0) {
+            fprintf(err, "[ERRO] when given flag -b (--bed), flag -f (--feature) is not allowed\n");
+            return 255;
+        }
+        fprintf(err, by_gtf ? "[INFO] read GTF file ...\n" : "[INFO] read BED file ...\n");
+        nf = read_features(o, by_bed, &fs, err);
+        if (nf < 0) return 255;
+        fprintf(err, "[INFO] %ld %s features loaded\n", nf, by_gtf ? "GTF" : "BED");
+        types = (char **)malloc((size_t)(nf + 1) * sizeof *types);
+        for (long i = 0; i < nf; i++) {
+            int seen = 0;
+            for (long t = 0; t < ntypes; t++) if (strcmp(types[t], fs[i].type) == 0) seen = 1;
+            if (!seen) types[ntypes++] = fs[i].type;
+        }
+    }
+    uint8_t *wrapbuf = NULL, *sub = NULL; size_t wrapcap = 0, subcap = 0;
+    char *name = NULL; size_t namecap = 0;
+    int rcode = 0;
+    for (int f = 0; f < nfiles && rcode == 0; f++) {
+        ora_reader *r = ora_reader_open(files[f], -1, o->guess_len);
+        if (!r) { fprintf(err, "[ERRO] open %s: no such file or directory\n", files[f]); rcode = 255; break; }
+        ora_record rec; int rc;
+        while ((rc = ora_reader_next(r, &rec)) == 1) {
+            const int fastq = ora_reader_is_fastq(r);
+            const int width = fastq ? 0 : o->line_width;                         /* subseq.go:316-318 */
+            const int64_t len = (int64_t)rec.seq_len;
+            if (by_region) {                                                     /* subseq.go:352-355 */
+                int64_t s, e; size_t m = 0, a = 0;
+                if (ora_sub_location(len, start, end, &s, &e) && e >= s) { a = (size_t)(s - 1); m = (size_t)(e - s + 1); }
+                if (fastq) {
+                    fputc('@', out); fwrite(rec.name, 1, rec.name_len, out); fputc('\n', out);
+                    fwrite(rec.seq + a, 1, m, out); fputs("\n+\n", out);
+                    fwrite(rec.qual + a, 1, m, out); fputc('\n', out);
+                } else {
+                    write_fasta(out, (const char *)rec.name, rec.name_len, rec.seq + a, m, width, &wrapbuf, &wrapcap);
+                }
+                continue;
+            }
+            if (!by_gtf && !by_bed) continue;
+            for (long t = 0; t < ntypes; t++) {
+                for (long i = 0; i < nf; i++) {
+                    const feature *ft = &fs[i];
+                    if (strcmp(ft->type, types[t]) != 0) continue;
+                    if (strlen(ft->chr) != rec.id_len || strncasecmp(ft->chr, (const char *)rec.name, rec.id_len) != 0) continue;
+                    int64_t s = ft->start, e = ft->end;                          /* subseq.go:379-420, 471-512 */
+                    const int minus = ft->strand == '-';
+                    if (minus) {
+                        if (o->only_flank) {
+                            if (o->up_stream > 0) { s = ft->end + 1; e = ft->end + o->up_stream; }
+                            else { s = ft->start - o->down_stream; e = ft->start - 1; }
+                        } else { s = ft->start - o->down_stream; e = ft->end + o->up_stream; }
+                    } else {
+                        if (o->only_flank) {
+                            if (o->up_stream > 0) { s = ft->start - o->up_stream; e = ft->start - 1; }
+                            else { s = e + 1; e = e + o->down_stream; }
+                        } else { s = ft->start - o->up_stream; e = ft->end + o->down_stream; }
+                    }
+                    if (s < 1) s = 1;
+                    if (e > len) e = len;
+                    int64_t a, b; size_t m = 0, a0 = 0;
+                    if (ora_sub_location(len, s, e, &a, &b) && b >= a) { a0 = (size_t)(a - 1); m = (size_t)(b - a + 1); }
+                    if (m + 1 > subcap) { subcap = m + 1; sub = (uint8_t *)realloc(sub, subcap); }
+                    memcpy(sub, rec.seq + a0, m);
+                    if (minus) ora_revcom_inplace(sub, NULL, m, ora_reader_alphabet(r));
+                    char flank[96] = "";                                         /* subseq.go:434-452 */
+                    if (o->up_stream > 0) {
+                        if (o->only_flank) snprintf(flank, sizeof flank, "_usf:%d", o->up_stream);
+                        else if (o->down_stream > 0) snprintf(flank, sizeof flank, "_us:%d_ds:%d", o->up_stream, o->down_stream);
+                        else snprintf(flank, sizeof flank, "_us:%d", o->up_stream);
+                    } else if (o->down_stream > 0) {
+                        if (o->only_flank) snprintf(flank, sizeof flank, "_dsf:%d", o->down_stream);
+                        else snprintf(flank, sizeof flank, "_ds:%d", o->down_stream);
+                    }
+                    size_t need = rec.id_len + strlen(ft->label) + 160;
+                    if (need > namecap) { namecap = need; name = (char *)realloc(name, namecap); }
+                    int nl = snprintf(name, namecap, "%.*s_%lld-%lld:%c%s %s", (int)rec.id_len, (const char *)rec.name,
+                                      (long long)ft->start, (long long)ft->end, ft->strand ? ft->strand : '.', flank, ft->label);
+                    write_fasta(out, name, (size_t)nl, sub, m, width, &wrapbuf, &wrapcap);
+                }
+            }
+        }
+        ora_reader_close(r);
+        if (rc < 0) { fprintf(err, "[ERRO] error when parsing %s\n", files[f]); rcode = 255; }
+    }
+    for (long i = 0; i < nf; i++) { free(fs[i].chr); free(fs[i].type); free(fs[i].label); }
+    free(fs); free(types); free(wrapbuf); free(sub); free(name);
+    return rcode;
 }

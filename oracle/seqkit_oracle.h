@@ -144,6 +144,41 @@ typedef struct ora_stats_opts {
 } ora_stats_opts;
 int ora_cmd_stats(const ora_stats_opts *o, int nfiles, const char **files, FILE *out, FILE *err);
 
+/* ---- subseq ---- */
+/* bio/seq SubLocation (unpinned module; called at seqkit/cmd/subseq.go:231 and, through
+ * (*Seq).SubSeq, at :353,399,419,491,511): turns the 1-based, inclusive, possibly negative
+ * (start, end) of a region into a 1-based inclusive range of a sequence of `length` bytes.
+ * Returns 0 when the region selects nothing (SubSeq then yields an empty sequence).  Pinned by
+ * the region table of doc/docs/usage.md:408-419 and tests/test.sh:109-137; the result for
+ * end == 0 (only reachable from the feature modes) is parity unpinned. */
+int ora_sub_location(int64_t length, int64_t start, int64_t end, int64_t *s, int64_t *e);
+
+/* One output record of subseq over a CSR batch: SubSeq(start, end) of record `record`, then
+ * RevComInplace when `minus` (subseq.go:399,491).  `ora_batch_subseq` writes the slices back
+ * to back into out_seq (and out_qual when qual != NULL; qualities are reversed, never
+ * complemented) and their offsets into out_offs[n+1]; out planes need the sum of the slice
+ * lengths, at most sum over slices of the source record's length.  lut = pair table of the
+ * alphabet (NULL: reverse only). */
+typedef struct ora_slice { uint64_t record; int64_t start, end; uint32_t minus, pad; } ora_slice;
+void ora_batch_subseq(const uint8_t *seq, const uint8_t *qual, const uint64_t *offs, uint64_t nrec,
+                      const ora_slice *slices, uint64_t n, const uint8_t *lut,
+                      uint8_t *out_seq, uint8_t *out_qual, uint64_t *out_offs);
+
+/* seqkit/cmd/subseq.go:53-347 on the streaming path (:301-343; the FASTA-index shortcut of
+ * :202-298 gives the same records in map order and is not restated).  Feature types are taken
+ * in order of first appearance in the GTF file (the reference iterates a Go map there). */
+typedef struct ora_subseq_opts {
+    const char *region;        /* -r */
+    const char *gtf, *bed;     /* --gtf --bed */
+    const char *gtf_tag;       /* --gtf-tag (default gene_id) */
+    int nchr; const char **chr;        /* --chr */
+    int nfeature; const char **feature; /* --feature */
+    int up_stream, down_stream, only_flank;   /* -u -d -f */
+    int line_width;
+    size_t guess_len;
+} ora_subseq_opts;
+int ora_cmd_subseq(const ora_subseq_opts *o, int nfiles, const char **files, FILE *out, FILE *err);
+
 #ifdef __cplusplus
 }
 #endif

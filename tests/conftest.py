@@ -79,6 +79,8 @@ def check_vector(cli, name, vec):
     with open(os.path.join(GOLDEN, "expected", name + ".txt"), "rb") as fh:
         want = fh.read()
     rc, got, err = run_cli(cli, vec["argv"], vec.get("stdin"))
+    if vec.get("pipe") and rc == 0:                      # `cmd ... | cmd <pipe argv>`
+        rc, got, err = run_cli(cli, vec["pipe"], got.decode("latin-1"))
     mode = vec["mode"]
     if mode == "stderr255":
         assert rc == 255 and got == b"" and err == want

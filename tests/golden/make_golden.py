@@ -66,6 +66,66 @@ STDIN = {
 }
 
 
+def unescape(t):
+    return t.replace("\\t", "\t").replace("\\n", "\n")
+
+
+def subseq_vectors(ref, out_dir, manifest):
+    """subseq known answers: the assertions of tests/test.sh:104-166 (every command there is
+    piped through `seq -s -w 0`) and the worked examples of doc/docs/usage.md:408-419, 455-496.
+    The small GTF / FASTA inputs those lines spell out are written next to this script."""
+    import re
+    with open(os.path.join(ref, "tests/test.sh"), encoding="utf-8") as fh:
+        sh = fh.read().split("\n")
+    with open(os.path.join(ref, "doc/docs/usage.md"), encoding="utf-8") as fh:
+        md = fh.read().split("\n")
+    pipe = ["seq", "-s", "-w", "0"]
+
+    def add(name, source, argv, stdin, want, note):
+        with open(os.path.join(out_dir, name + ".txt"), "w", encoding="utf-8") as fh:
+            fh.write(want)
+        manifest[name] = {"source": source, "argv": argv, "pipe": pipe, "mode": "exact", "note": note, "stdin": stdin}
+
+    # test.sh:105  echo -e ">seq\nacgtnACGTN"
+    testseq = unescape(re.search(r'echo -e "([^"]*)"', sh[104]).group(1)) + "\n"
+    for cmd_line, assert_line in ((110, 113), (116, 119), (122, 125), (128, 131), (134, 137)):
+        region = re.search(r"subseq -r (\S+)", sh[cmd_line - 1]).group(1)
+        want = re.search(r"assert_equal (\S+) ", sh[assert_line - 1]).group(1) + "\n"
+        add("G11_subseq_region_%d" % cmd_line, "tests/test.sh:%d,%d" % (cmd_line, assert_line),
+            ["subseq", "-r", region], testseq, want, "region " + region)
+    # test.sh:142  gtf="..." (two CDS features on 4..6, one per strand)
+    gtf = unescape(re.search(r'gtf="(.*)"$', sh[141]).group(1).replace('\\"', '"'))
+    with open(os.path.join(HERE, "subseq_test.gtf"), "w") as fh:
+        fh.write(gtf)
+    for cmd_line, assert_line in ((145, 148), (151, 154), (157, 160), (163, 166)):
+        flags = re.search(r"--gtf <\(echo -ne \$gtf\)(.*?) \|", sh[cmd_line - 1]).group(1).split()
+        want = unescape(re.search(r'echo -e "([^"]*)"', sh[assert_line - 1]).group(1)) + "\n"
+        add("G12_subseq_gtf_%d" % cmd_line, "tests/test.sh:%d,%d (md5 of this text)" % (cmd_line, assert_line),
+            ["subseq", "--gtf", "subseq_test.gtf"] + flags, testseq, want, "GTF features, flags " + " ".join(flags))
+    # usage.md:410-419  region table on ACGTNacgtn
+    row = md[409].split()
+    assert row[0] == "seq"
+    table_seq = ">seq\n" + "".join(row[1:]) + "\n"
+    for ln in range(411, 420):
+        f = md[ln - 1].split()
+        add("G13_subseq_table_%d" % ln, "doc/docs/usage.md:410,%d" % ln, ["subseq", "-r", f[0]], table_seq,
+            "".join(f[1:]) + "\n", "region table row " + f[0])
+    # usage.md:455-467, 484-496: t.fa, t.gtf and three outputs.  The documented head lines use an older
+    # name layout (seq_5:8:.) than the code of this tree (seq_5-8:., subseq.go:453), so only the
+    # sequences are compared.
+    with open(os.path.join(HERE, "subseq_doc.fa"), "w") as fh:
+        fh.write(md[455].strip() + "\n" + md[456].strip() + "\n")
+    with open(os.path.join(HERE, "subseq_doc.gtf"), "w") as fh:
+        for ln in (460, 461):
+            f = md[ln - 1].split()
+            fh.write("\t".join(f[:8]) + "\t" + " ".join(f[8:]) + "\n")
+    for name, cmd_line, rows in (("G14_subseq_doc_gtf", 463, (465, 467)), ("G14_subseq_doc_gtf_u3", 484, (486, 488)),
+                                 ("G14_subseq_doc_gtf_u3f", 492, (494, 496))):
+        flags = md[cmd_line - 1].split("t.fa")[1].split()
+        add(name, "doc/docs/usage.md:%d-%d" % (cmd_line, rows[1]), ["subseq", "--gtf", "subseq_doc.gtf", "subseq_doc.fa"] + flags,
+            None, "".join(md[r - 1].strip() + "\n" for r in rows), "documented GTF example, sequences only")
+
+
 def main(ref):
     out_dir = os.path.join(HERE, "expected")
     os.makedirs(out_dir, exist_ok=True)
@@ -89,6 +149,7 @@ def main(ref):
     manifest["G3b_hairpin_lengths"] = {"source": "tests/hairpin.fa.fai column 2", "mode": "lengths",
                                        "argv": ["fx2tab", "hairpin.fa.gz", "-n", "-l"], "stdin": None,
                                        "note": "record lengths in file order"}
+    subseq_vectors(ref, out_dir, manifest)
     with open(os.path.join(out_dir, "manifest.json"), "w") as fh:
         json.dump(manifest, fh, indent=1, sort_keys=True)
     print("wrote %d vectors to %s" % (len(manifest), out_dir))
