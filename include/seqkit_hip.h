@@ -135,6 +135,44 @@ int skh_validate_dev(skh_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_offse
                      uint64_t total_bytes, const uint8_t valid[256], uint64_t limit,
                      skh_validate_result *d_out, void *stream);
 
+/* Subsequences: what `seqkit subseq` does to a record (seqkit/cmd/subseq.go:352-355 for
+ * -r, :378-420 for GTF features, :470-512 for BED features): record.Seq.SubSeq(start, end),
+ * followed by RevComInplace() for a feature on the minus strand (subseq.go:399,491).  A slice
+ * names a record of the batch and SubSeq's arguments: 1-based, inclusive, negative positions
+ * counting from the end, resolved with seq.SubLocation's rules (region table of
+ * doc/docs/usage.md:408-419).  The output is a new batch with one record per slice, in slice
+ * order: d_out_seq (and d_out_qual when d_qual is given; qualities are reversed with their
+ * bases, never complemented) packed back to back, d_out_offsets[n+1] its offsets.
+ * d_slices == NULL is the region mode: slice i is record i (n must equal nrec) with the
+ * uniform start / end / minus arguments.  lut: complement table for minus slices (NULL:
+ * reverse only).  The outcome goes to DEVICE memory d_result: out_bytes = total length of
+ * the slices; status SKH_SUBSEQ_ECAPACITY when that exceeds out_capacity (nothing valid was
+ * written; retry with larger planes), SKH_SUBSEQ_ERECORD when slice bad_slice names a record
+ * >= nrec.  Output planes follow the batch layout rule (16-byte aligned, allocated to
+ * skh_padded_size(out_capacity)); d_workspace is 256-byte aligned scratch of
+ * skh_subseq_workspace_size(n) bytes. */
+#define SKH_SUBSEQ_OK        0
+#define SKH_SUBSEQ_ERECORD   1
+#define SKH_SUBSEQ_ECAPACITY 2
+typedef struct skh_slice {
+    uint64_t record;       /* source record in the batch               */
+    int64_t  start, end;   /* SubSeq(start, end)                        */
+    uint32_t minus;        /* != 0: reverse-complement the subsequence  */
+    uint32_t reserved;
+} skh_slice;
+typedef struct skh_subseq_result {
+    uint64_t out_bytes;
+    uint32_t status;       /* SKH_SUBSEQ_* */
+    uint32_t reserved;
+    uint64_t bad_slice;
+} skh_subseq_result;
+uint64_t skh_subseq_workspace_size(uint64_t n);
+int skh_subseq_dev(skh_ctx *ctx, const uint8_t *d_seq, const uint8_t *d_qual, const uint64_t *d_offsets,
+                   uint64_t nrec, uint64_t total_bytes, const skh_slice *d_slices, uint64_t n,
+                   int64_t start, int64_t end, int minus, const uint8_t *lut,
+                   uint8_t *d_out_seq, uint8_t *d_out_qual, uint64_t out_capacity, uint64_t *d_out_offsets,
+                   void *d_workspace, uint64_t workspace_bytes, skh_subseq_result *d_result, void *stream);
+
 /* ---- FASTA/FASTQ text -> batch on the device ----------------------------------------
  * The step before the hot path: replaces the serial record scanner behind
  * fastx.NewReader / reader.Read() (call sites seqkit/cmd/seq.go:115-127,
@@ -283,6 +321,18 @@ int skh_text_validate(skh_ctx *ctx, skh_text *t, const uint8_t valid[256], uint6
 int skh_text_truncate(skh_ctx *ctx, skh_text *t, uint64_t nrec);
 /* Where record `record`'s name lies in the block's text buffer. */
 int skh_text_name(skh_ctx *ctx, skh_text *t, uint64_t record, uint64_t *pos, uint32_t *len);
+/* name_pos / name_len of records [first, first+count) copied to host memory; the names
+ * themselves lie in skh_text_buffer(). */
+int skh_text_names(skh_ctx *ctx, skh_text *t, uint64_t first, uint64_t count, uint64_t *pos, uint32_t *len);
+/* skh_subseq_dev on the block: afterwards the block holds the n slices as its records, and
+ * every later call on it (format, count, stats, validate) sees those.  `slices` is host memory
+ * (NULL = region mode with start / end / minus, n ignored).  names == NULL keeps the names of
+ * the source records (region mode only); otherwise record i of the result is named
+ * names[name_pos[i] .. name_pos[i]+name_len[i]) (host memory, names_bytes in all), as the
+ * feature modes rename their records (subseq.go:453,542). */
+int skh_text_subseq(skh_ctx *ctx, skh_text *t, const skh_slice *slices, uint64_t n, int64_t start, int64_t end,
+                    int minus, const uint8_t *lut, const uint8_t *names, uint64_t names_bytes,
+                    const uint64_t *name_pos, const uint32_t *name_len);
 /* skh_stats_dev on the block, merged into *inout. */
 int skh_text_stats(skh_ctx *ctx, skh_text *t, const uint8_t is_gap[256], skh_stats_partial *inout);
 

@@ -43,6 +43,15 @@ class TabFormat(C.Structure):
 TAB_LENGTH, TAB_GC, TAB_GC_SKEW, TAB_CONTENT = 0, 1, 2, 3
 
 
+class Slice(C.Structure):
+    _fields_ = [("record", C.c_uint64), ("start", C.c_int64), ("end", C.c_int64), ("minus", C.c_uint32),
+                ("reserved", C.c_uint32)]
+
+
+class SubseqResult(C.Structure):
+    _fields_ = [("out_bytes", C.c_uint64), ("status", C.c_uint32), ("reserved", C.c_uint32), ("bad_slice", C.c_uint64)]
+
+
 class ValidateResult(C.Structure):
     _fields_ = [("record", C.c_uint64), ("offset", C.c_uint64), ("letter", C.c_uint32), ("found", C.c_uint32)]
 
@@ -83,6 +92,12 @@ SYMBOLS = {
     "skh_text_validate": (C.c_int, [vp, vp, u8p, C.c_uint64, C.POINTER(ValidateResult)]),
     "skh_text_truncate": (C.c_int, [vp, vp, C.c_uint64]),
     "skh_text_name": (C.c_int, [vp, vp, C.c_uint64, u64p, C.POINTER(C.c_uint32)]),
+    "skh_subseq_workspace_size": (C.c_uint64, [C.c_uint64]),
+    "skh_subseq_dev": (C.c_int, [vp, vp, vp, vp, C.c_uint64, C.c_uint64, vp, C.c_uint64, C.c_int64, C.c_int64, C.c_int,
+                                 u8p, vp, vp, C.c_uint64, vp, vp, C.c_uint64, vp, vp]),
+    "skh_text_names": (C.c_int, [vp, vp, C.c_uint64, C.c_uint64, u64p, C.POINTER(C.c_uint32)]),
+    "skh_text_subseq": (C.c_int, [vp, vp, C.POINTER(Slice), C.c_uint64, C.c_int64, C.c_int64, C.c_int, u8p, u8p,
+                                  C.c_uint64, u64p, C.POINTER(C.c_uint32)]),
     "skh_text_alloc": (C.c_int, [vp, C.c_uint64, C.POINTER(vp)]),
     "skh_text_free": (None, [vp]),
     "skh_text_buffer": (vp, [vp]),

@@ -361,6 +361,36 @@ int skh_validate_dev(skh_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_offse
 
 // ---------------------------------------------------------------- text -> batch
 
+uint64_t skh_subseq_workspace_size(uint64_t n) { return skh::subseq_workspace_size(n); }
+
+int skh_subseq_dev(skh_ctx* ctx, const uint8_t* d_seq, const uint8_t* d_qual, const uint64_t* d_offsets, uint64_t nrec,
+                   uint64_t total_bytes, const skh_slice* d_slices, uint64_t n, int64_t start, int64_t end, int minus,
+                   const uint8_t* lut, uint8_t* d_out_seq, uint8_t* d_out_qual, uint64_t out_capacity,
+                   uint64_t* d_out_offsets, void* d_workspace, uint64_t workspace_bytes, skh_subseq_result* d_result,
+                   void* stream)
+{
+    static_assert(sizeof(skh_slice) == sizeof(skh::Slice) && sizeof(skh_subseq_result) == sizeof(skh::SubseqResult),
+                  "ABI structs mirror the kernel structs");
+    if (!ctx || !d_out_offsets || !d_workspace || !d_result) return fail(SKH_EINVAL, "NULL argument");
+    if (int rc = check_plane_args(d_seq, d_offsets, nrec, total_bytes)) return rc;
+    if (!d_out_seq || (d_qual && !d_out_qual)) return fail(SKH_EINVAL, "NULL output plane");
+    if ((reinterpret_cast<uintptr_t>(d_out_seq) & 15) || (reinterpret_cast<uintptr_t>(d_out_qual) & 15))
+        return fail(SKH_EINVAL, "output planes must be 16-byte aligned");
+    if (reinterpret_cast<uintptr_t>(d_workspace) & 255) return fail(SKH_EINVAL, "workspace must be 256-byte aligned");
+    if (!d_slices && n != nrec && n != 0) return fail(SKH_EINVAL, "region mode needs one slice per record");
+    if (n >= (1ull << 40)) return fail(SKH_EINVAL, "too many slices");
+    if (workspace_bytes < skh::subseq_workspace_size(n)) return fail(SKH_ECAPACITY, "subseq workspace too small");
+    HIP_TRY(hipSetDevice(ctx->device));
+    skh::Table256 t;
+    if (lut) memcpy(t.v, lut, 256);
+    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
+    HIP_TRY(skh::launch_subseq(cfg_for(ctx, nrec, total_bytes), d_seq, d_qual, d_offsets, nrec,
+                               reinterpret_cast<const skh::Slice*>(d_slices), n, start, end, minus ? 1u : 0u,
+                               lut ? &t : nullptr, d_out_seq, d_out_qual, out_capacity, d_out_offsets, d_workspace,
+                               reinterpret_cast<skh::SubseqResult*>(d_result), st));
+    return SKH_OK;
+}
+
 uint64_t skh_parse_workspace_size(uint64_t text_bytes, uint64_t max_lines)
 {
     return skh::parse_workspace_size(text_bytes, max_lines ? max_lines : 1);
@@ -703,7 +733,7 @@ struct skh_text {
     uint64_t *d_offs = nullptr, *d_npos = nullptr;
     uint32_t* d_nlen = nullptr;
     void *d_ws = nullptr, *d_fws = nullptr;
-    uint64_t ws_bytes = 0, fws_bytes = 0;
+    uint64_t ws_bytes = 0, fws_bytes = 0, fws_records = 0;
     uint8_t *d_out = nullptr, *h_out = nullptr;
     uint64_t out_cap = 0;
     void* h_res = nullptr;                  // pinned: results come back here
@@ -712,6 +742,19 @@ struct skh_text {
     int fastq = 0;
     uint64_t nrec = 0, seq_bytes = 0, text_bytes = 0;
     bool transformed = false;               // planes of the block now live in d_seq2 / d_qual2
+    // what the later calls read: the parsed tables, or those of the slices after skh_text_subseq
+    const uint64_t *v_offs = nullptr, *v_npos = nullptr;
+    const uint32_t* v_nlen = nullptr;
+    const uint8_t* v_text = nullptr;
+    // skh_text_subseq: slice list, offsets and names of the result
+    uint64_t plane_cap = 0;                 // bytes of d_seq2 / d_qual2
+    skh::Slice* d_slices = nullptr;
+    uint64_t *d_offs2 = nullptr, *d_npos2 = nullptr;
+    uint32_t* d_nlen2 = nullptr;
+    void* d_sws = nullptr;
+    uint64_t slice_cap = 0;
+    uint8_t* d_names = nullptr;
+    uint64_t names_cap = 0;
     uint64_t* d_counts[SKH_TAB_MAX_PASSES] = {nullptr, nullptr, nullptr, nullptr};   // results of skh_text_count
     uint64_t counts_cap[SKH_TAB_MAX_PASSES] = {0, 0, 0, 0};
     uint32_t nclass[SKH_TAB_MAX_PASSES] = {0, 0, 0, 0};
@@ -731,6 +774,7 @@ hipError_t text_alloc_lines(skh_text* t, uint64_t max_lines)
     t->max_lines = max_lines;
     t->ws_bytes = skh::parse_workspace_size(t->cap, max_lines);
     t->fws_bytes = skh::format_workspace_size(max_lines);
+    t->fws_records = max_lines;
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&t->d_offs), (max_lines + 1) * 8);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&t->d_npos), max_lines * 8);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&t->d_nlen), max_lines * 4);
@@ -767,6 +811,7 @@ int skh_text_alloc(skh_ctx* ctx, uint64_t block_bytes, skh_text** out)
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&t->d_qual), t->cap);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&t->d_seq2), t->cap);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&t->d_qual2), t->cap);
+    t->plane_cap = t->cap;
     if (e == hipSuccess) e = hipHostMalloc(&t->h_res, 256, hipHostMallocDefault);
     if (e == hipSuccess) e = hipMalloc(&t->d_res, 256);
     if (e == hipSuccess) e = text_alloc_lines(t, t->cap / 32 + 1024);
@@ -788,6 +833,8 @@ void skh_text_free(skh_text* t)
     text_free_lines(t);
     (void)hipFree(t->d_text); (void)hipFree(t->d_seq); (void)hipFree(t->d_qual); (void)hipFree(t->d_seq2); (void)hipFree(t->d_qual2);
     (void)hipFree(t->d_out); (void)hipFree(t->d_res);
+    (void)hipFree(t->d_slices); (void)hipFree(t->d_offs2); (void)hipFree(t->d_npos2); (void)hipFree(t->d_nlen2);
+    (void)hipFree(t->d_sws); (void)hipFree(t->d_names);
     for (auto& c : t->d_counts) (void)hipFree(c);
     (void)hipHostFree(t->h_text); (void)hipHostFree(t->h_out); (void)hipHostFree(t->h_res);
     delete t;
@@ -821,6 +868,7 @@ int skh_text_parse(skh_ctx* ctx, skh_text* t, uint64_t text_bytes, int format, i
     t->seq_bytes = out->status == SKH_PARSE_OK ? out->seq_bytes : 0;
     t->text_bytes = text_bytes;
     t->transformed = false;
+    t->v_offs = t->d_offs; t->v_npos = t->d_npos; t->v_nlen = t->d_nlen; t->v_text = t->d_text;
     return SKH_OK;
 }
 
@@ -829,7 +877,7 @@ int skh_text_offsets(skh_ctx* ctx, skh_text* t, uint64_t first, uint64_t count, 
     if (!ctx || !t || !offsets) return fail(SKH_EINVAL, "NULL argument");
     if (first + count > t->nrec + 1) return fail(SKH_EINVAL, "offset range beyond the block's records");
     HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipMemcpyAsync(offsets, t->d_offs + first, count * 8, hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(hipMemcpyAsync(offsets, t->v_offs + first, count * 8, hipMemcpyDeviceToHost, t->stream));
     HIP_TRY(hipStreamSynchronize(t->stream));
     return SKH_OK;
 }
@@ -872,7 +920,7 @@ int skh_text_format_seq(skh_ctx* ctx, skh_text* t, const skh_seq_format* fmt, co
     const uint8_t* qual = t->fastq ? (t->transformed ? t->d_qual2 : t->d_qual) : nullptr;
     if (fmt->print_qual && !qual) return fail(SKH_EINVAL, "quality requested for a FASTA block");
     for (;;) {
-        int rc = skh_format_seq_dev(ctx, t->d_text, t->d_npos, t->d_nlen, seq, qual, t->d_offs, t->nrec, fmt, t->d_out,
+        int rc = skh_format_seq_dev(ctx, t->v_text, t->v_npos, t->v_nlen, seq, qual, t->v_offs, t->nrec, fmt, t->d_out,
                                     t->out_cap, t->d_fws, t->fws_bytes, static_cast<skh_format_result*>(t->d_res),
                                     t->stream);
         if (rc) return rc;
@@ -906,7 +954,7 @@ int skh_text_count(skh_ctx* ctx, skh_text* t, const uint8_t class_of[256], uint3
     }
     t->nclass[pass] = nclass;
     if (t->nrec == 0) return SKH_OK;
-    return skh_count_dev(ctx, t->transformed ? t->d_seq2 : t->d_seq, t->d_offs, t->nrec, t->seq_bytes, class_of, nclass,
+    return skh_count_dev(ctx, t->transformed ? t->d_seq2 : t->d_seq, t->v_offs, t->nrec, t->seq_bytes, class_of, nclass,
                          t->d_counts[pass], t->stream);
 }
 
@@ -920,7 +968,7 @@ int skh_text_format_tab(skh_ctx* ctx, skh_text* t, const skh_tab_format* fmt, co
     const uint8_t* qual = t->fastq ? (t->transformed ? t->d_qual2 : t->d_qual) : nullptr;
     if (fmt->print_qual && !qual) return fail(SKH_EINVAL, "quality requested for a FASTA block");
     for (;;) {
-        int rc = skh_format_tab_dev(ctx, t->d_text, t->d_npos, t->d_nlen, seq, qual, t->d_offs, t->nrec, t->d_counts,
+        int rc = skh_format_tab_dev(ctx, t->v_text, t->v_npos, t->v_nlen, seq, qual, t->v_offs, t->nrec, t->d_counts,
                                     t->nclass, fmt, t->d_out, t->out_cap, t->d_fws, t->fws_bytes,
                                     static_cast<skh_format_result*>(t->d_res), t->stream);
         if (rc) return rc;
@@ -945,7 +993,7 @@ int skh_text_validate(skh_ctx* ctx, skh_text* t, const uint8_t valid[256], uint6
     memset(out, 0, sizeof *out);
     if (t->nrec == 0) return SKH_OK;
     HIP_TRY(hipSetDevice(ctx->device));
-    int rc = skh_validate_dev(ctx, t->transformed ? t->d_seq2 : t->d_seq, t->d_offs, t->nrec, t->seq_bytes, valid, limit,
+    int rc = skh_validate_dev(ctx, t->transformed ? t->d_seq2 : t->d_seq, t->v_offs, t->nrec, t->seq_bytes, valid, limit,
                               static_cast<skh_validate_result*>(t->d_res), t->stream);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(t->h_res, t->d_res, sizeof(skh_validate_result), hipMemcpyDeviceToHost, t->stream));
@@ -960,7 +1008,7 @@ int skh_text_truncate(skh_ctx* ctx, skh_text* t, uint64_t nrec)
     if (nrec > t->nrec) return fail(SKH_EINVAL, "cannot truncate to more records than the block holds");
     if (nrec == t->nrec) return SKH_OK;
     HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipMemcpyAsync(t->h_res, t->d_offs + nrec, 8, hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(hipMemcpyAsync(t->h_res, t->v_offs + nrec, 8, hipMemcpyDeviceToHost, t->stream));
     HIP_TRY(hipStreamSynchronize(t->stream));
     t->seq_bytes = *static_cast<uint64_t*>(t->h_res);
     t->nrec = nrec;
@@ -973,11 +1021,94 @@ int skh_text_name(skh_ctx* ctx, skh_text* t, uint64_t record, uint64_t* pos, uin
     if (record >= t->nrec) return fail(SKH_EINVAL, "record beyond the block");
     HIP_TRY(hipSetDevice(ctx->device));
     uint8_t* h = static_cast<uint8_t*>(t->h_res);
-    HIP_TRY(hipMemcpyAsync(h, t->d_npos + record, 8, hipMemcpyDeviceToHost, t->stream));
-    HIP_TRY(hipMemcpyAsync(h + 8, t->d_nlen + record, 4, hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(hipMemcpyAsync(h, t->v_npos + record, 8, hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(hipMemcpyAsync(h + 8, t->v_nlen + record, 4, hipMemcpyDeviceToHost, t->stream));
     HIP_TRY(hipStreamSynchronize(t->stream));
     memcpy(pos, h, 8);
     memcpy(len, h + 8, 4);
+    return SKH_OK;
+}
+
+int skh_text_names(skh_ctx* ctx, skh_text* t, uint64_t first, uint64_t count, uint64_t* pos, uint32_t* len)
+{
+    if (!ctx || !t || ((!pos || !len) && count)) return fail(SKH_EINVAL, "NULL argument");
+    if (first + count > t->nrec) return fail(SKH_EINVAL, "record range beyond the block");
+    if (count == 0) return SKH_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpyAsync(pos, t->v_npos + first, count * 8, hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(hipMemcpyAsync(len, t->v_nlen + first, count * 4, hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    return SKH_OK;
+}
+
+int skh_text_subseq(skh_ctx* ctx, skh_text* t, const skh_slice* slices, uint64_t n, int64_t start, int64_t end, int minus,
+                    const uint8_t* lut, const uint8_t* names, uint64_t names_bytes, const uint64_t* name_pos,
+                    const uint32_t* name_len)
+{
+    if (!ctx || !t) return fail(SKH_EINVAL, "NULL argument");
+    if (t->transformed) return fail(SKH_EINVAL, "block was already transformed");
+    if (!slices) n = t->nrec;
+    if (!names && slices) return fail(SKH_EINVAL, "a slice list needs names for its records");
+    if (names && (!name_pos || !name_len)) return fail(SKH_EINVAL, "NULL name table");
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (n + 1 > t->slice_cap) {
+        (void)hipFree(t->d_slices); (void)hipFree(t->d_offs2); (void)hipFree(t->d_npos2); (void)hipFree(t->d_nlen2);
+        (void)hipFree(t->d_sws);
+        t->d_slices = nullptr; t->d_offs2 = t->d_npos2 = nullptr; t->d_nlen2 = nullptr; t->d_sws = nullptr; t->slice_cap = 0;
+        const uint64_t cap = n + n / 4 + 1024;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&t->d_slices), cap * sizeof(skh::Slice)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&t->d_offs2), (cap + 1) * 8));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&t->d_npos2), cap * 8));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&t->d_nlen2), cap * 4));
+        HIP_TRY(hipMalloc(&t->d_sws, skh::subseq_workspace_size(cap)));
+        t->slice_cap = cap;
+    }
+    if (names && names_bytes + 16 > t->names_cap) {
+        (void)hipFree(t->d_names); t->d_names = nullptr; t->names_cap = 0;
+        const uint64_t cap = names_bytes + names_bytes / 4 + 4096;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&t->d_names), cap));
+        t->names_cap = cap;
+    }
+    if (slices && n) HIP_TRY(hipMemcpyAsync(t->d_slices, slices, n * sizeof(skh_slice), hipMemcpyHostToDevice, t->stream));
+    if (names && n) {
+        HIP_TRY(hipMemcpyAsync(t->d_names, names, names_bytes, hipMemcpyHostToDevice, t->stream));
+        HIP_TRY(hipMemcpyAsync(t->d_npos2, name_pos, n * 8, hipMemcpyHostToDevice, t->stream));
+        HIP_TRY(hipMemcpyAsync(t->d_nlen2, name_len, n * 4, hipMemcpyHostToDevice, t->stream));
+    }
+    for (;;) {
+        int rc = skh_subseq_dev(ctx, t->d_seq, t->fastq ? t->d_qual : nullptr, t->d_offs, t->nrec, t->seq_bytes,
+                                slices ? reinterpret_cast<const skh_slice*>(t->d_slices) : nullptr, n, start, end, minus, lut,
+                                t->d_seq2, t->fastq ? t->d_qual2 : nullptr, t->plane_cap, t->d_offs2, t->d_sws,
+                                skh::subseq_workspace_size(t->slice_cap), static_cast<skh_subseq_result*>(t->d_res),
+                                t->stream);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(t->h_res, t->d_res, sizeof(skh_subseq_result), hipMemcpyDeviceToHost, t->stream));
+        HIP_TRY(hipStreamSynchronize(t->stream));
+        const skh_subseq_result r = *static_cast<skh_subseq_result*>(t->h_res);
+        if (r.status == SKH_SUBSEQ_ERECORD) return fail(SKH_EINVAL, "a slice names a record beyond the block");
+        if (r.status == SKH_SUBSEQ_OK) {
+            t->seq_bytes = r.out_bytes;
+            break;
+        }
+        // overlapping features can select more bases than the block holds: larger planes, again
+        (void)hipFree(t->d_seq2); (void)hipFree(t->d_qual2);
+        t->d_seq2 = t->d_qual2 = nullptr; t->plane_cap = 0;
+        const uint64_t cap = skh_padded_size(r.out_bytes + r.out_bytes / 8 + 4096);
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&t->d_seq2), cap));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&t->d_qual2), cap));
+        t->plane_cap = cap;
+    }
+    t->nrec = n;
+    t->transformed = true;
+    t->v_offs = t->d_offs2;
+    if (names) { t->v_text = t->d_names; t->v_npos = t->d_npos2; t->v_nlen = t->d_nlen2; }
+    // the per-record tables of the formatter are sized by the parser's line count
+    if (n > t->fws_records) {
+        (void)hipFree(t->d_fws); t->d_fws = nullptr;
+        t->fws_records = n + n / 4;
+        t->fws_bytes = skh::format_workspace_size(t->fws_records);
+        HIP_TRY(hipMalloc(&t->d_fws, t->fws_bytes));
+    }
     return SKH_OK;
 }
 
@@ -986,7 +1117,7 @@ int skh_text_stats(skh_ctx* ctx, skh_text* t, const uint8_t is_gap[256], skh_sta
     if (!ctx || !t || !is_gap || !inout) return fail(SKH_EINVAL, "NULL argument");
     if (t->nrec == 0) return SKH_OK;
     HIP_TRY(hipSetDevice(ctx->device));
-    int rc = skh_stats_dev(ctx, t->transformed ? t->d_seq2 : t->d_seq, t->d_offs, t->nrec, t->seq_bytes, is_gap,
+    int rc = skh_stats_dev(ctx, t->transformed ? t->d_seq2 : t->d_seq, t->v_offs, t->nrec, t->seq_bytes, is_gap,
                            static_cast<skh_stats_partial*>(t->d_res), t->stream);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(t->h_res, t->d_res, sizeof(skh_stats_partial), hipMemcpyDeviceToHost, t->stream));

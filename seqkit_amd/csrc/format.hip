@@ -339,6 +339,17 @@ static inline uint64_t up256(uint64_t x) { return (x + 255) & ~255ull; }
 
 }  // namespace
 
+uint64_t scan64_partials(uint64_t n) { return (n + FSCAN_TILE - 1) / FSCAN_TILE + 1; }
+
+hipError_t launch_scan64(const uint64_t* v, uint64_t n, uint64_t* out, uint64_t* part, uint64_t* total, hipStream_t s)
+{
+    const uint64_t npart = (n + FSCAN_TILE - 1) / FSCAN_TILE ? (n + FSCAN_TILE - 1) / FSCAN_TILE : 1;
+    hipLaunchKernelGGL(k_scan_partials64, dim3((uint32_t)npart), dim3(FB), 0, s, v, n, part);
+    hipLaunchKernelGGL(k_scan_top64, dim3(1), dim3(1024), 0, s, part, npart, total);
+    hipLaunchKernelGGL(k_scan_apply64, dim3((uint32_t)npart), dim3(FB), 0, s, v, n, part, out);
+    return hipGetLastError();
+}
+
 uint64_t format_workspace_size(uint64_t nrec)
 {
     const uint64_t npart = (nrec + FSCAN_TILE - 1) / FSCAN_TILE + 1;

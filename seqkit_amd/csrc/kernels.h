@@ -104,4 +104,23 @@ uint64_t format_workspace_size(uint64_t nrec);
 hipError_t launch_format_seq(const FormatSeqArgs& a, uint8_t* out, uint64_t out_capacity, void* workspace,
                              FormatResult* res, hipStream_t s);
 
+// exclusive scan of n uint64 values (format.hip): out[i] = v[0] + ... + v[i-1], *total = the sum.
+// `part` holds scan64_partials(n) values of scratch.
+uint64_t scan64_partials(uint64_t n);
+hipError_t launch_scan64(const uint64_t* v, uint64_t n, uint64_t* out, uint64_t* part, uint64_t* total, hipStream_t s);
+
+// ---- subsequences (slices.hip) --------------------------------------------------------------
+
+enum : uint32_t { SUBSEQ_OK = 0, SUBSEQ_ERECORD = 1, SUBSEQ_ECAPACITY = 2 };
+struct Slice { uint64_t record; int64_t start, end; uint32_t minus, pad; };             // mirrors skh_slice
+struct SubseqResult { uint64_t out_bytes; uint32_t status, pad; uint64_t bad_slice; };  // mirrors skh_subseq_result
+
+uint64_t subseq_workspace_size(uint64_t n);
+// slices == nullptr: slice i = record i with the uniform (start, end, minus); n must equal nrec then.
+// lut: complement table applied to minus-strand slices (nullptr: reverse only).  qual/out_qual may be nullptr.
+hipError_t launch_subseq(const LaunchCfg& cfg, const uint8_t* seq, const uint8_t* qual, const uint64_t* offs,
+                         uint64_t nrec, const Slice* slices, uint64_t n, int64_t start, int64_t end, uint32_t minus,
+                         const Table256* lut, uint8_t* out_seq, uint8_t* out_qual, uint64_t capacity,
+                         uint64_t* out_offs, void* workspace, SubseqResult* res, hipStream_t st);
+
 }  // namespace skh
