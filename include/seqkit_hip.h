@@ -235,6 +235,9 @@ typedef struct skh_seq_format {
     int32_t line_width;
     uint8_t print_name, print_seq, print_qual, plus_line, only_id;
     char    mark;               /* '>' or '@' */
+    uint8_t empty_as_fasta;     /* != 0: a record without bases is printed as FASTA ('>' name, an empty
+                                 * line, no quality), as fastx Record.FormatToWriter chooses the layout
+                                 * per record by "has qualities" (subseq.go:354) */
 } skh_seq_format;
 typedef struct skh_format_result {
     uint64_t out_bytes;

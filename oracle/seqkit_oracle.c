@@ -903,7 +903,9 @@ int ora_cmd_subseq(const ora_subseq_opts *o, int nfiles, const char **files, FIL
             if (by_region) {                                                     /* subseq.go:352-355 */
                 int64_t s, e; size_t m = 0, a = 0;
                 if (ora_sub_location(len, start, end, &s, &e) && e >= s) { a = (size_t)(s - 1); m = (size_t)(e - s + 1); }
-                if (fastq) {
+                /* Record.FormatToWriter picks the layout by "has qualities": a FASTQ record whose
+                 * subsequence is empty has none left and prints as FASTA (parity unpinned) */
+                if (fastq && m > 0) {
                     fputc('@', out); fwrite(rec.name, 1, rec.name_len, out); fputc('\n', out);
                     fwrite(rec.seq + a, 1, m, out); fputs("\n+\n", out);
                     fwrite(rec.qual + a, 1, m, out); fputc('\n', out);

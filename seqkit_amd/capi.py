@@ -28,7 +28,7 @@ class ParseResult(C.Structure):
 class SeqFormat(C.Structure):
     _fields_ = [("min_len", C.c_int64), ("max_len", C.c_int64), ("line_width", C.c_int32),
                 ("print_name", C.c_uint8), ("print_seq", C.c_uint8), ("print_qual", C.c_uint8),
-                ("plus_line", C.c_uint8), ("only_id", C.c_uint8), ("mark", C.c_char)]
+                ("plus_line", C.c_uint8), ("only_id", C.c_uint8), ("mark", C.c_char), ("empty_as_fasta", C.c_uint8)]
 
 
 class TabColumn(C.Structure):

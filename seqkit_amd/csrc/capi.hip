@@ -384,7 +384,7 @@ int skh_subseq_dev(skh_ctx* ctx, const uint8_t* d_seq, const uint8_t* d_qual, co
     skh::Table256 t;
     if (lut) memcpy(t.v, lut, 256);
     hipStream_t st = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
-    HIP_TRY(skh::launch_subseq(cfg_for(ctx, nrec, total_bytes), d_seq, d_qual, d_offsets, nrec,
+    HIP_TRY(skh::launch_subseq(cfg_for(ctx, nrec, total_bytes), d_seq, d_qual, d_offsets, nrec, total_bytes,
                                reinterpret_cast<const skh::Slice*>(d_slices), n, start, end, minus ? 1u : 0u,
                                lut ? &t : nullptr, d_out_seq, d_out_qual, out_capacity, d_out_offsets, d_workspace,
                                reinterpret_cast<skh::SubseqResult*>(d_result), st));
@@ -447,6 +447,7 @@ int skh_format_seq_dev(skh_ctx* ctx, const uint8_t* d_text, const uint64_t* d_na
     a.width = (uint32_t)fmt->line_width;
     a.print_name = fmt->print_name != 0; a.print_seq = fmt->print_seq != 0; a.print_qual = fmt->print_qual != 0;
     a.plus_line = fmt->plus_line != 0; a.only_id = fmt->only_id != 0; a.mark = (uint8_t)fmt->mark;
+    a.empty_fasta = fmt->empty_as_fasta != 0;
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
     HIP_TRY(skh::launch_format_seq(a, d_out, out_capacity, d_workspace, reinterpret_cast<skh::FormatResult*>(d_result), st));

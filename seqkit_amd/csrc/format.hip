@@ -49,7 +49,7 @@ __global__ __launch_bounds__(FB) void k_fmt_sizes(const FormatSeqArgs a, uint64_
                 sz += (a.print_seq ? 1 : 0) + (uint64_t)nl + 1;
             }
             if (a.print_seq) sz += wrapped_len(len, a.width) + 1;
-            if (a.print_qual) sz += (a.plus_line ? 2 : 0) + wrapped_len(len, a.width) + 1;
+            if (a.print_qual && !(a.empty_fasta && len == 0)) sz += (a.plus_line ? 2 : 0) + wrapped_len(len, a.width) + 1;
         }
         size[r] = sz;
         shown_name[r] = nl;
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(FB) void k_fmt_write(const FormatSeqArgs a, const u
         const uint64_t s = a.offsets[r], len = a.offsets[r + 1] - s;
         if (a.print_name) {
             const uint32_t nl = shown_name[r];
-            if (a.print_seq) { if (j == 0) *o = a.mark; o++; }
+            if (a.print_seq) { if (j == 0) *o = (a.empty_fasta && len == 0) ? (uint8_t)'>' : a.mark; o++; }
             copy_plain<G>(o, a.text + a.name_pos[r], nl, j);
             if (j == 0) o[nl] = '\n';
             o += nl + 1;
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(FB) void k_fmt_write(const FormatSeqArgs a, const u
             if (j == 0) o[w] = '\n';
             o += w + 1;
         }
-        if (a.print_qual) {
+        if (a.print_qual && !(a.empty_fasta && len == 0)) {
             if (a.plus_line) { if (j == 0) { o[0] = '+'; o[1] = '\n'; } o += 2; }
             copy_wrapped<G>(o, a.qual + s, len, a.width, j);
             const uint64_t w = wrapped_len(len, a.width);

@@ -76,6 +76,7 @@ struct FormatSeqArgs {
     int64_t min_len, max_len;     // < 0 = no limit
     uint32_t width;               // line width of sequence and quality (0 = no wrapping)
     uint8_t print_name, print_seq, print_qual, plus_line, only_id, mark;
+    uint8_t empty_fasta;          // a record without bases: '>' head, no quality part
 };
 
 struct FormatResult { uint64_t out_bytes; uint32_t status; uint32_t pad; };
@@ -119,7 +120,7 @@ uint64_t subseq_workspace_size(uint64_t n);
 // slices == nullptr: slice i = record i with the uniform (start, end, minus); n must equal nrec then.
 // lut: complement table applied to minus-strand slices (nullptr: reverse only).  qual/out_qual may be nullptr.
 hipError_t launch_subseq(const LaunchCfg& cfg, const uint8_t* seq, const uint8_t* qual, const uint64_t* offs,
-                         uint64_t nrec, const Slice* slices, uint64_t n, int64_t start, int64_t end, uint32_t minus,
+                         uint64_t nrec, uint64_t total_in, const Slice* slices, uint64_t n, int64_t start, int64_t end, uint32_t minus,
                          const Table256* lut, uint8_t* out_seq, uint8_t* out_qual, uint64_t capacity,
                          uint64_t* out_offs, void* workspace, SubseqResult* res, hipStream_t st);
 

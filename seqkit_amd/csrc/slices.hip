@@ -11,10 +11,12 @@
 //   2. exclusive scan of the lengths = offsets of the output batch;
 //   3. copy: every lane owns one aligned 16-byte chunk of the OUTPUT plane (so slices of any
 //      length, from one byte to a whole chromosome, spread evenly over the grid).  A wavefront
-//      finds the slices holding its first and last byte with two 64-ary searches of the offsets,
-//      each lane then bisects between them.  A chunk inside one slice is one unaligned 16-byte
-//      load (byte-reversed and looked up for a minus-strand slice) and one 16-byte store; a
-//      chunk that spans slice borders is gathered byte by byte.
+//      serves runs of consecutive 1-KiB spans: one 64-ary search of the offsets finds the slice
+//      under the run's first byte, after that it walks forward, copying the offsets and sources
+//      of the slices under each span into LDS with whole-wavefront loads; each lane bisects
+//      that table.  A chunk inside one slice is one unaligned 16-byte load (byte-reversed and
+//      looked up for a minus-strand slice) and one 16-byte store; a chunk that spans slice
+//      borders is gathered byte by byte from the table.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -59,8 +61,7 @@ __global__ void k_slice_init(SubseqResult* res)
 __global__ __launch_bounds__(SB) void k_slice_resolve(const uint64_t* __restrict__ offs, uint64_t nrec,
                                                       const Slice* __restrict__ slices, uint64_t n, int64_t start,
                                                       int64_t end, uint32_t minus, uint64_t* __restrict__ src,
-                                                      uint64_t* __restrict__ len, uint8_t* __restrict__ flags,
-                                                      SubseqResult* __restrict__ res)
+                                                      uint64_t* __restrict__ len, SubseqResult* __restrict__ res)
 {
     for (uint64_t i = (uint64_t)blockIdx.x * SB + threadIdx.x; i < n; i += (uint64_t)gridDim.x * SB) {
         uint64_t rec = i;
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(SB) void k_slice_resolve(const uint64_t* __restrict
                 sl = (uint64_t)(e - s + 1);
             }
         }
-        src[i] = sp; len[i] = sl; flags[i] = m ? 1 : 0;
+        src[i] = sp | (m ? 1ull << 63 : 0); len[i] = sl;      // bit 63: minus strand
     }
 }
 
@@ -90,20 +91,31 @@ __global__ void k_slice_finish(const uint64_t* __restrict__ total, uint64_t n, u
     if (res->status == SUBSEQ_OK && *total > capacity) res->status = SUBSEQ_ECAPACITY;
 }
 
-// byte t of the output chunk at o, gathered from whichever slice holds it; r = a slice at or before it
-template <bool COMP>
-__device__ __forceinline__ uint4 gather_chunk(const uint8_t* __restrict__ in, const uint64_t* __restrict__ src,
-                                              const uint64_t* __restrict__ oo, const uint8_t* __restrict__ flags,
-                                              uint64_t r, uint64_t o, int nbytes, const uint8_t* s_lut)
+constexpr uint64_t MINUS = 1ull << 63;                 // top bit of a resolved source position: minus strand
+constexpr int SL_T = 256;                                // slice-table entries a wavefront keeps in LDS
+constexpr int SL_RUN = 16;                               // consecutive 1-KiB spans a wavefront serves per search
+
+struct SliceLds {
+    uint8_t lut[256];
+    uint64_t oo[SB / 64][SL_T];                          // output offsets of a stretch of slices
+    uint64_t src[SB / 64][SL_T];
+};
+
+// Bytes [0, nbytes) of the output chunk at o, gathered from whichever slices hold them.  `oo` and
+// `src` are indexed from slice r (global arrays from 0, or a wavefront's LDS table from its first
+// slice); r = a slice at or before the one holding byte o.
+template <bool COMP, typename TO, typename TS>
+__device__ __forceinline__ uint4 gather_chunk(const uint8_t* __restrict__ in, TS src, TO oo, uint64_t r, uint64_t o,
+                                              int nbytes, const uint8_t* s_lut)
 {
     uint32_t w[4] = {0, 0, 0, 0};
 #pragma unroll 1
     for (int t = 0; t < nbytes; t++) {
         const uint64_t p = o + (uint64_t)t;
-        while (oo[r + 1] <= p) r++;                       // p < oo[n]: terminates
-        const uint64_t os = oo[r], l = oo[r + 1] - os, k = p - os;
-        const bool rev = flags[r] != 0;
-        uint32_t b = in[src[r] + (rev ? l - 1 - k : k)];
+        while (oo[r + 1] <= p) r++;                       // p < the last offset: terminates
+        const uint64_t os = oo[r], l = oo[r + 1] - os, k = p - os, sv = src[r];
+        const bool rev = (sv & MINUS) != 0;
+        uint32_t b = in[(sv & ~MINUS) + (rev ? l - 1 - k : k)];
         if (COMP && rev) b = s_lut[b];
         const uint32_t v = b << (8 * (t & 3)), m = (uint32_t)t >> 2;
         w[0] |= m == 0 ? v : 0u; w[1] |= m == 1 ? v : 0u; w[2] |= m == 2 ? v : 0u; w[3] |= m == 3 ? v : 0u;
@@ -111,47 +123,175 @@ __device__ __forceinline__ uint4 gather_chunk(const uint8_t* __restrict__ in, co
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
+// the output chunk at o, which starts in slice [os, oe) with resolved source sv
+template <bool COMP>
+__device__ __forceinline__ uint4 whole_chunk(const uint8_t* __restrict__ in, uint64_t sv, uint64_t os, uint64_t oe,
+                                             uint64_t o, const uint8_t* s_lut)
+{
+    const uint64_t k = o - os, l = oe - os, base = sv & ~MINUS;
+    if (sv & MINUS) {
+        uint4 v = reverse16(ldu16(in + base + (l - 16 - k)));
+        if (COMP) v = map16(v, s_lut);
+        return v;
+    }
+    return ldu16(in + base + k);
+}
+
+// 16-byte mask with bytes [a, b) set (0 <= a <= b <= 16)
+__device__ __forceinline__ uint4 byte_range_mask(int a, int b)
+{
+    auto upto = [](int k, int half) -> uint64_t {          // bytes below k of the 8-byte half
+        const int n = k - 8 * half;
+        return n <= 0 ? 0ull : (n >= 8 ? ~0ull : (1ull << (8 * n)) - 1ull);
+    };
+    const uint64_t lo = upto(b, 0) & ~upto(a, 0), hi = upto(b, 1) & ~upto(a, 1);
+    return make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+}
+
+// byte t of the result is byte t - n of v (0 <= n < 16); the n lowest bytes are zero
+__device__ __forceinline__ uint4 shift_up_bytes(uint4 v, int n)
+{
+    uint64_t lo = (uint64_t)v.x | ((uint64_t)v.y << 32), hi = (uint64_t)v.z | ((uint64_t)v.w << 32);
+    if (n >= 8) { hi = lo; lo = 0; n -= 8; }
+    if (n) { hi = (hi << (8 * n)) | (lo >> (64 - 8 * n)); lo <<= 8 * n; }
+    return make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+}
+
+constexpr int SL_SEG = 4;                                // segments of a chunk whose windows are loaded together
+
 template <bool COMP>
 __global__ __launch_bounds__(SB) void k_slice_copy(const uint8_t* __restrict__ in, const uint64_t* __restrict__ src,
-                                                   const uint64_t* __restrict__ oo, const uint8_t* __restrict__ flags,
-                                                   uint64_t n, Table256 lut, uint8_t* __restrict__ out,
-                                                   uint64_t capacity, const SubseqResult* __restrict__ res)
+                                                   const uint64_t* __restrict__ oo, uint64_t n, uint64_t in_padded,
+                                                   Table256 lut, uint8_t* __restrict__ out,
+                                                   const SubseqResult* __restrict__ res)
 {
-    __shared__ uint8_t s_lut[256];
-    if (COMP) s_lut[threadIdx.x] = lut.v[threadIdx.x];
+    __shared__ SliceLds L;
+    if (COMP) L.lut[threadIdx.x] = lut.v[threadIdx.x];
     __syncthreads();
     if (res->status != SUBSEQ_OK) return;
     const uint64_t total = res->out_bytes;
-    const uint32_t lane = threadIdx.x & 63;
-    const uint64_t nwave = (total + 1023) >> 10;          // 1 KiB of output per wavefront and step
-    for (uint64_t wv = (uint64_t)blockIdx.x * (SB / 64) + (threadIdx.x >> 6); wv < nwave;
-         wv += (uint64_t)gridDim.x * (SB / 64)) {
-        const uint64_t w0 = wv << 10;
-        const uint64_t wlast = (w0 + 1024 < total ? w0 + 1024 : total) - 1;
-        const uint64_t r_lo = find_record(oo, n, w0);
-        const uint64_t r_hi = oo[r_lo + 1] > wlast ? r_lo : find_record(oo, n, wlast);
-        const uint64_t o = w0 + 16ull * lane;
-        if (o >= total) continue;
-        uint64_t lo = r_lo, hi = r_hi + 1;                // oo[lo] <= o < oo[hi]
-        while (hi - lo > 1) {
-            const uint64_t mid = (lo + hi) >> 1;
-            if (oo[mid] <= o) lo = mid; else hi = mid;
-        }
-        const uint64_t os = oo[lo], oe = oo[lo + 1];
-        uint4 v;
-        if (o + 16 <= oe) {                                // the whole chunk lies in slice lo
-            const uint64_t k = o - os, l = oe - os;
-            if (flags[lo]) {
-                v = reverse16(ldu16(in + src[lo] + (l - 16 - k)));
-                if (COMP) v = map16(v, s_lut);
-            } else {
-                v = ldu16(in + src[lo] + k);
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint64_t* t_oo = L.oo[wave];
+    uint64_t* t_src = L.src[wave];
+    const uint64_t nspan = (total + 1023) >> 10;           // 1 KiB of output per wavefront and step
+    const uint64_t nrun = (nspan + SL_RUN - 1) / SL_RUN;
+    for (uint64_t run = (uint64_t)blockIdx.x * (SB / 64) + wave; run < nrun; run += (uint64_t)gridDim.x * (SB / 64)) {
+        const uint64_t sp_end = (run + 1) * SL_RUN < nspan ? (run + 1) * SL_RUN : nspan;
+        uint64_t r_lo = find_record(oo, n, (run * SL_RUN) << 10);      // slice holding the run's first byte
+        // The table: offsets and sources of slices tbase .. tbase + tcount - 1, fetched 64 at a time with
+        // whole-wavefront loads and kept while the spans of the run walk through it (a table of
+        // 150-byte slices lasts for tens of spans, one of chromosome-long slices is a single entry).
+        uint64_t tbase = 0;
+        uint32_t tcount = 0;
+        bool have = false;
+        for (uint64_t sp = run * SL_RUN; sp < sp_end; sp++) {
+            const uint64_t w0 = sp << 10;
+            const uint64_t wlast = (w0 + 1024 < total ? w0 + 1024 : total) - 1;
+            const uint64_t o = w0 + 16ull * lane;
+            // first table entry after the span's first slice whose offset lies past the span
+            uint32_t rs = (uint32_t)(r_lo - tbase);
+            auto scan = [&]() -> int {
+                for (uint32_t k = rs >> 6; k < (tcount >> 6); k++) {
+                    const uint32_t idx = 64u * k + lane;
+                    const unsigned long long m = __ballot(idx > rs && t_oo[idx] > wlast);
+                    if (m) return (int)(64u * k) + (int)__builtin_ctzll(m);
+                }
+                return -1;
+            };
+            int j = have && r_lo - tbase < (uint64_t)tcount ? scan() : -1;
+            while (j < 0) {
+                if (!have || tcount == SL_T || r_lo - tbase >= (uint64_t)tcount) {
+                    if (have && r_lo == tbase && tcount == SL_T) break;       // SL_T slices do not reach the span's end
+                    tbase = r_lo; tcount = 0; rs = 0; have = true;
+                }
+                __builtin_amdgcn_wave_barrier();
+                const uint64_t idx = tbase + tcount + lane;
+                t_oo[tcount + lane] = idx <= n ? oo[idx] : ~0ull;
+                t_src[tcount + lane] = idx < n ? src[idx] : 0;
+                tcount += 64;
+                __builtin_amdgcn_wave_barrier();
+                j = scan();
             }
-            *reinterpret_cast<uint4*>(out + o) = v;
-        } else {
-            const int nb = total - o < 16 ? (int)(total - o) : 16;
-            v = gather_chunk<COMP>(in, src, oo, flags, lo, o, nb, s_lut);
-            store_clipped(out, 0, total, o, v);
+            if (j < 0) {
+                // more than SL_T slices under one span (slices of a few bytes): global tables, bisected per lane
+                const uint64_t r_hi = find_record(oo, n, wlast);
+                if (o < total) {
+                    uint64_t lo = r_lo, hi = r_hi + 1;     // oo[lo] <= o < oo[hi]
+                    while (hi - lo > 1) {
+                        const uint64_t mid = (lo + hi) >> 1;
+                        if (oo[mid] <= o) lo = mid; else hi = mid;
+                    }
+                    const uint64_t os = oo[lo], oe = oo[lo + 1];
+                    if (o + 16 <= oe) {
+                        *reinterpret_cast<uint4*>(out + o) = whole_chunk<COMP>(in, src[lo], os, oe, o, L.lut);
+                    } else {
+                        const int nb = total - o < 16 ? (int)(total - o) : 16;
+                        store_clipped(out, 0, total, o, gather_chunk<COMP>(in, src, oo, lo, o, nb, L.lut));
+                    }
+                }
+                r_lo = r_hi;
+                continue;
+            }
+            // A chunk is cut into segments, one per slice under it (one segment = the whole chunk for
+            // most chunks of long slices).  A segment's source bytes are the 16-byte window that
+            // puts them at their place in the chunk; the windows of up to SL_SEG segments are all
+            // requested before the first is used, then masked and merged.  What is left (a fifth
+            // slice under one chunk, a window that would reach past the ends of the plane) is gathered
+            // byte by byte.
+            if (o < total) {
+                const int nb = total - o < 16 ? (int)(total - o) : 16;
+                uint32_t ri = rs, hi = (uint32_t)j;        // t_oo[ri] <= o < t_oo[hi]
+                while (hi - ri > 1) {
+                    const uint32_t mid = (ri + hi) >> 1;
+                    if (t_oo[mid] <= o) ri = mid; else hi = mid;
+                }
+                uint4 W[SL_SEG];
+                int tb[SL_SEG];
+                bool rev[SL_SEG];
+                int ta = 0;                                 // bytes [0, ta) of the chunk are accounted for
+                bool bytewise = false;
+#pragma unroll
+                for (int g = 0; g < SL_SEG; g++) {
+                    tb[g] = ta;
+                    rev[g] = false;
+                    W[g] = make_uint4(0, 0, 0, 0);
+                    if (ta < nb && !bytewise) {
+                        while (t_oo[ri + 1] <= o + (uint64_t)ta) ri++;          // o + ta < total: stops inside the table
+                        const uint64_t os = t_oo[ri], oe = t_oo[ri + 1], sv = t_src[ri], base = sv & ~MINUS;
+                        rev[g] = (sv & MINUS) != 0;
+                        // byte t of the chunk is in[A + t] (plus strand) or in[A + 15 - t] (minus strand)
+                        const int64_t A = rev[g] ? (int64_t)(base + (oe - os) - 16) - (int64_t)(o - os)
+                                                 : (int64_t)base + (int64_t)(o - os);
+                        if (A < 0 || (uint64_t)A + 16 > in_padded) {
+                            bytewise = true;
+                        } else {
+                            W[g] = ldu16(in + A);
+                            tb[g] = oe - o < (uint64_t)nb ? (int)(oe - o) : nb;
+                            ta = tb[g];
+                        }
+                    }
+                }
+                uint4 v = make_uint4(0, 0, 0, 0);
+                int t0 = 0;
+#pragma unroll
+                for (int g = 0; g < SL_SEG; g++) {
+                    uint4 x = W[g];
+                    if (rev[g]) {
+                        x = reverse16(x);
+                        if (COMP) x = map16(x, L.lut);
+                    }
+                    const uint4 m = byte_range_mask(t0, tb[g]);
+                    v.x |= x.x & m.x; v.y |= x.y & m.y; v.z |= x.z & m.z; v.w |= x.w & m.w;
+                    t0 = tb[g];
+                }
+                if (ta < nb) {                              // the rest, one byte at a time
+                    const uint4 r = gather_chunk<COMP>(in, t_src, t_oo, (uint64_t)ri, o + (uint64_t)ta, nb - ta, L.lut);
+                    const uint4 sh = shift_up_bytes(r, ta);
+                    v.x |= sh.x; v.y |= sh.y; v.z |= sh.z; v.w |= sh.w;
+                }
+                store_clipped(out, 0, total, o, v);
+            }
+            r_lo = tbase + (uint64_t)(j - 1);              // the slice holding the span's last byte
         }
     }
 }
@@ -162,11 +302,11 @@ static inline uint64_t up256(uint64_t x) { return (x + 255) & ~255ull; }
 
 uint64_t subseq_workspace_size(uint64_t n)
 {
-    return up256(8) + up256(n * 8) + up256(n * 8) + up256(n) + up256(scan64_partials(n) * 8);
+    return up256(8) + up256(n * 8) + up256(n * 8) + up256(scan64_partials(n) * 8);
 }
 
 hipError_t launch_subseq(const LaunchCfg& cfg, const uint8_t* seq, const uint8_t* qual, const uint64_t* offs,
-                         uint64_t nrec, const Slice* slices, uint64_t n, int64_t start, int64_t end, uint32_t minus,
+                         uint64_t nrec, uint64_t total_in, const Slice* slices, uint64_t n, int64_t start, int64_t end, uint32_t minus,
                          const Table256* lut, uint8_t* out_seq, uint8_t* out_qual, uint64_t capacity,
                          uint64_t* out_offs, void* workspace, SubseqResult* res, hipStream_t st)
 {
@@ -174,24 +314,29 @@ hipError_t launch_subseq(const LaunchCfg& cfg, const uint8_t* seq, const uint8_t
     uint64_t* total = reinterpret_cast<uint64_t*>(ws); ws += up256(8);
     uint64_t* src = reinterpret_cast<uint64_t*>(ws); ws += up256(n * 8);
     uint64_t* len = reinterpret_cast<uint64_t*>(ws); ws += up256(n * 8);
-    uint8_t* flags = ws; ws += up256(n);
     uint64_t* part = reinterpret_cast<uint64_t*>(ws);
     auto capped = [](uint64_t b) { return (uint32_t)(b < 1 ? 1 : (b > 16384 ? 16384 : b)); };
     hipLaunchKernelGGL(k_slice_init, dim3(1), dim3(1), 0, st, res);
     hipLaunchKernelGGL(k_slice_resolve, dim3(capped((n + SB - 1) / SB)), dim3(SB), 0, st, offs, nrec, slices, n, start, end,
-                       minus, src, len, flags, res);
+                       minus, src, len, res);
     hipError_t e = launch_scan64(len, n, out_offs, part, total, st);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_slice_finish, dim3(1), dim3(1), 0, st, total, n, out_offs, capacity, res);
     // the output size is only known on the device: the grid is sized for the capacity and strides
-    const uint64_t want = (capacity + 4095) / 4096;
-    const uint64_t cap = (uint64_t)(cfg.n_cu ? cfg.n_cu : 256) * 8;
+    const uint64_t want = (capacity + 1024ull * SL_RUN * (SB / 64) - 1) / (1024ull * SL_RUN * (SB / 64));
+    static int occ = 0;                                  // resident workgroups per CU (the same for both instantiations)
+    if (occ == 0) {
+        int v = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, k_slice_copy<true>, SB, 0) != hipSuccess || v < 1) v = 4;
+        occ = v > 8 ? 8 : v;
+    }
+    const uint64_t cap = (uint64_t)(cfg.n_cu ? cfg.n_cu : 256) * (uint64_t)occ;
     const uint32_t g = (uint32_t)(want < 1 ? 1 : (want > cap ? cap : want));
     const Table256 none = {};
-    if (lut) hipLaunchKernelGGL(k_slice_copy<true>, dim3(g), dim3(SB), 0, st, seq, src, out_offs, flags, n, *lut, out_seq, capacity, res);
-    else hipLaunchKernelGGL(k_slice_copy<false>, dim3(g), dim3(SB), 0, st, seq, src, out_offs, flags, n, none, out_seq, capacity, res);
-    if (qual)
-        hipLaunchKernelGGL(k_slice_copy<false>, dim3(g), dim3(SB), 0, st, qual, src, out_offs, flags, n, none, out_qual, capacity, res);
+    const uint64_t in_padded = (total_in + 15) & ~15ull;
+    if (lut) hipLaunchKernelGGL(k_slice_copy<true>, dim3(g), dim3(SB), 0, st, seq, src, out_offs, n, in_padded, *lut, out_seq, res);
+    else hipLaunchKernelGGL(k_slice_copy<false>, dim3(g), dim3(SB), 0, st, seq, src, out_offs, n, in_padded, none, out_seq, res);
+    if (qual) hipLaunchKernelGGL(k_slice_copy<false>, dim3(g), dim3(SB), 0, st, qual, src, out_offs, n, in_padded, none, out_qual, res);
     return hipGetLastError();
 }
 

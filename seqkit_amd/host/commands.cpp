@@ -732,4 +732,276 @@ int cmd_stats(const GlobalOpts& g, const StatsOpts& o, const std::vector<std::st
     return 0;
 }
 
+// ------------------------------------------------------------------------------------ subseq
+namespace {
+
+struct Feature {
+    std::string chr, type, label;      // chr and type lower-cased (subseq.go:156,160,189); label = tag value / BED name
+    std::string strand;                // "+", "-", or "" when not given
+    long long start = 0, end = 0;      // 1-based, inclusive
+};
+
+std::string lower(std::string s)
+{
+    for (auto& c : s) c = (char)tolower((unsigned char)c);
+    return s;
+}
+
+std::vector<std::string> split_tabs(const std::string& line, size_t max_items)
+{
+    std::vector<std::string> it;
+    size_t a = 0;
+    while (it.size() + 1 < max_items) {
+        const size_t t = line.find('\t', a);
+        if (t == std::string::npos) break;
+        it.push_back(line.substr(a, t - a));
+        a = t + 1;
+    }
+    it.push_back(line.substr(a));
+    return it;
+}
+
+// value of `tag` in a GTF attribute column: tag "value"; tag2 "value2";
+std::string gtf_tag_value(const std::string& attrs, const std::string& tag)
+{
+    size_t p = 0;
+    while (p < attrs.size()) {
+        while (p < attrs.size() && (attrs[p] == ' ' || attrs[p] == ';')) p++;
+        size_t q = p;
+        while (q < attrs.size() && attrs[q] != ';') {
+            if (attrs[q] == '"') { q++; while (q < attrs.size() && attrs[q] != '"') q++; if (q < attrs.size()) q++; }
+            else q++;
+        }
+        if (q - p > tag.size() && attrs.compare(p, tag.size(), tag) == 0 && attrs[p + tag.size()] == ' ') {
+            size_t v = p + tag.size() + 1, ve = q;
+            while (ve > v && attrs[ve - 1] == ' ') ve--;
+            if (ve - v >= 2 && attrs[v] == '"' && attrs[ve - 1] == '"') { v++; ve--; }
+            return attrs.substr(v, ve - v);
+        }
+        p = q;
+    }
+    return "";
+}
+
+bool in_list_ci(const std::string& v, const std::vector<std::string>& list)
+{
+    const std::string l = lower(v);
+    for (auto& x : list) if (lower(x) == l) return true;
+    return false;
+}
+
+// GTF (gtf.ReadFilteredFeatures, subseq.go:146-152) or BED (cmd/bed.go:52-121) features, plain or gzip
+bool read_features(const SubseqOpts& o, bool is_bed, std::vector<Feature>& out, std::string& err)
+{
+    const std::string& path = is_bed ? o.bed : o.gtf;
+    gzFile fh = gzopen(path.c_str(), "rb");
+    if (!fh) { err = "open " + path + ": no such file or directory"; return false; }
+    gzbuffer(fh, 1 << 20);
+    std::string line;
+    std::vector<char> buf(1 << 16);
+    bool more = true;
+    while (more) {
+        line.clear();
+        for (;;) {
+            if (!gzgets(fh, buf.data(), (int)buf.size())) { more = false; break; }
+            line += buf.data();
+            if (!line.empty() && line.back() == '\n') break;
+        }
+        if (!more && line.empty()) break;
+        while (!line.empty() && (line.back() == '\n' || line.back() == '\r')) line.pop_back();
+        if (line.empty() || line[0] == '#') continue;
+        Feature f;
+        if (is_bed) {
+            if ((line.size() > 7 && line.compare(0, 7, "browser") == 0) || (line.size() > 5 && line.compare(0, 5, "track") == 0)) continue;
+            const auto it = split_tabs(line, 64);
+            if (it.size() < 3) continue;
+            if (!o.chr.empty() && std::find(o.chr.begin(), o.chr.end(), it[0]) == o.chr.end()) continue;   // bed.go:75-79
+            char *e1 = nullptr, *e2 = nullptr;
+            const long long a = strtoll(it[1].c_str(), &e1, 10), b = strtoll(it[2].c_str(), &e2, 10);
+            if (it[1].empty() || *e1) { err = it[0] + ": bad start: " + it[1]; gzclose(fh); return false; }
+            if (it[2].empty() || *e2) { err = it[0] + ": bad end: " + it[2]; gzclose(fh); return false; }
+            if (a >= b) {
+                err = it[0] + ": start (" + std::to_string(a) + ") must be <= end (" + std::to_string(b) + ")";
+                gzclose(fh); return false;
+            }
+            if (it.size() >= 6 && it[5] != "+" && it[5] != "-") { err = "bad strand: " + it[5]; gzclose(fh); return false; }
+            f.chr = lower(it[0]); f.start = a + 1; f.end = b;
+            if (it.size() >= 4) f.label = it[3];
+            if (it.size() >= 6) f.strand = it[5];
+        } else {
+            const auto it = split_tabs(line, 9);
+            if (it.size() < 9) continue;
+            if (!o.chr.empty() && !in_list_ci(it[0], o.chr)) continue;
+            if (!o.feature.empty() && !in_list_ci(it[2], o.feature)) continue;
+            f.chr = lower(it[0]); f.type = lower(it[2]);
+            f.start = atoll(it[3].c_str()); f.end = atoll(it[4].c_str());
+            if (it[6] == "+" || it[6] == "-") f.strand = it[6];
+            f.label = gtf_tag_value(it[8], o.gtf_tag);
+        }
+        out.push_back(std::move(f));
+    }
+    gzclose(fh);
+    return true;
+}
+
+}  // namespace
+
+// subseq.go:53-347 on its streaming path (:301-343): per record SubSeq(start, end) for -r, or one
+// output record per GTF / BED feature of that sequence, reverse-complemented on the minus strand.
+// The slices are cut, reverse-complemented and printed on the GPU; the host only turns features
+// into (record, start, end, strand) and their names.  Features of one sequence are emitted by
+// type in order of first appearance in the file, then in file order (the reference walks a Go
+// map of types there).
+int cmd_subseq(const GlobalOpts& g, const SubseqOpts& o, const std::vector<std::string>& files)
+{
+    if (g.host_parse) return fatal("subseq has no --host-parse mode");
+    if (o.only_flank) {                                                       // subseq.go:94-102
+        if (o.up_stream > 0 && o.down_stream > 0)
+            return fatal("when flag -f (--only-flank) given, only one of flags -u (--up-stream) and -d (--down-stream) is allowed");
+        if (o.up_stream == 0 && o.down_stream == 0)
+            return fatal("when flag -f (--only-flank) given, one of flags -u (--up-stream) and -d (--down-stream) should be given");
+    }
+    const bool by_region = !o.region.empty(), by_gtf = !by_region && !o.gtf.empty(), by_bed = !by_region && !by_gtf && !o.bed.empty();
+    long long start = 0, end = 0;
+    if (by_region) {                                                          // subseq.go:103-138
+        if (o.up_stream > 0 || o.down_stream > 0 || o.only_flank)
+            return fatal("when flag -r (--region) given, any of flags -u (--up-stream), -d (--down-stream) and -f (--only-flank) is not allowed");
+        char *e1 = nullptr, *e2 = nullptr;
+        start = strtoll(o.region.c_str(), &e1, 10);
+        bool ok = e1 != o.region.c_str() && *e1 == ':';
+        if (ok) { end = strtoll(e1 + 1, &e2, 10); ok = e2 != e1 + 1 && *e2 == 0; }
+        if (!ok) return fatal("invalid region: " + o.region + ". type \"seqkit subseq -h\" for more examples");
+        if (start == 0 || end == 0) return fatal("both start and end should not be 0");
+        if (start < 0 && end > 0) return fatal("when start < 0, end should not > 0");
+    }
+    std::vector<Feature> feats;
+    std::vector<std::pair<std::string, std::vector<size_t>>> by_chr;          // features of a sequence in output order
+    if (by_gtf || by_bed) {
+        if (by_bed && !o.feature.empty()) return fatal("when given flag -b (--bed), flag -f (--feature) is not allowed");
+        if (!g.quiet) fprintf(stderr, by_gtf ? "[INFO] read GTF file ...\n" : "[INFO] read BED file ...\n");
+        std::string err;
+        if (!read_features(o, by_bed, feats, err)) return fatal(err);
+        if (!g.quiet) fprintf(stderr, "[INFO] %zu %s features loaded\n", feats.size(), by_gtf ? "GTF" : "BED");
+        std::vector<std::string> types;
+        for (auto& f : feats) if (std::find(types.begin(), types.end(), f.type) == types.end()) types.push_back(f.type);
+        std::vector<size_t> order(feats.size());
+        for (size_t i = 0; i < order.size(); i++) order[i] = i;
+        auto rank = [&](size_t i) { return (size_t)(std::find(types.begin(), types.end(), feats[i].type) - types.begin()); };
+        std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return rank(a) < rank(b); });
+        for (size_t i : order) {
+            auto it = std::find_if(by_chr.begin(), by_chr.end(), [&](const auto& kv) { return kv.first == feats[i].chr; });
+            if (it == by_chr.end()) { by_chr.emplace_back(feats[i].chr, std::vector<size_t>()); it = by_chr.end() - 1; }
+            it->second.push_back(i);
+        }
+        std::sort(by_chr.begin(), by_chr.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+    }
+    std::string flank;                                                        // subseq.go:434-452
+    if (o.up_stream > 0) {
+        if (o.only_flank) flank = "_usf:" + std::to_string(o.up_stream);
+        else if (o.down_stream > 0) flank = "_us:" + std::to_string(o.up_stream) + "_ds:" + std::to_string(o.down_stream);
+        else flank = "_us:" + std::to_string(o.up_stream);
+    } else if (o.down_stream > 0) {
+        flank = (o.only_flank ? "_dsf:" : "_ds:") + std::to_string(o.down_stream);
+    }
+
+    Ctx ctx;
+    if (skh_init(g.device, &ctx.c) != SKH_OK) return fatal(skh_last_error());
+    Sink out(g.out_file);
+    if (!out.ok()) return fatal("open " + g.out_file + ": cannot create");
+    std::vector<uint64_t> offs, npos, out_npos;
+    std::vector<uint32_t> nlen, out_nlen;
+    std::vector<skh_slice> slices;
+    std::string names;
+    for (const std::string& file : files) {
+        TextBlocks tb(ctx.c, file, g.text_block_bytes);
+        if (!tb.ok()) return fatal(tb.error());
+        uint8_t lut[256];
+        int ab = -1;
+        skh_parse_result res;
+        while (tb.next(res)) {
+            skh_text* t = tb.block();
+            if (res.nrec == 0) { tb.advance(res); continue; }
+            skh_seq_format f;
+            memset(&f, 0, sizeof f);
+            f.min_len = f.max_len = -1;
+            f.line_width = tb.is_fastq() ? 0 : g.line_width;                 // subseq.go:316-318
+            f.print_name = 1; f.print_seq = 1; f.plus_line = 1;
+            if (by_region) {
+                PhaseTimer pt(2);
+                if (skh_text_subseq(ctx.c, t, nullptr, 0, start, end, 0, nullptr, nullptr, 0, nullptr, nullptr) != SKH_OK)
+                    return fatal(skh_last_error());
+                f.print_qual = tb.is_fastq(); f.mark = tb.is_fastq() ? '@' : '>';
+                f.empty_as_fasta = 1;                                         // Record.FormatToWriter: layout per record
+            } else if (by_gtf || by_bed) {
+                if (ab < 0) {
+                    std::string err;
+                    ab = first_record_alphabet(ctx.c, t, g, g.alphabet, err);
+                    if (ab < 0) return fatal(err);
+                    skh_pair_table(ab, lut);
+                }
+                offs.resize(res.nrec + 1); npos.resize(res.nrec); nlen.resize(res.nrec);
+                if (skh_text_offsets(ctx.c, t, 0, res.nrec + 1, offs.data()) != SKH_OK) return fatal(skh_last_error());
+                if (skh_text_names(ctx.c, t, 0, res.nrec, npos.data(), nlen.data()) != SKH_OK) return fatal(skh_last_error());
+                slices.clear(); names.clear(); out_npos.clear(); out_nlen.clear();
+                const uint8_t* text = skh_text_buffer(t);
+                for (uint64_t r = 0; r < res.nrec; r++) {
+                    const uint8_t* name = text + npos[r];
+                    uint32_t idl = 0;
+                    while (idl < nlen[r] && !(name[idl] == ' ' || (name[idl] >= '\t' && name[idl] <= '\r'))) idl++;
+                    if (idl == 0) idl = nlen[r];
+                    const std::string id((const char*)name, idl), key = lower(id);
+                    auto it = std::lower_bound(by_chr.begin(), by_chr.end(), key, [](const auto& kv, const std::string& k) { return kv.first < k; });
+                    if (it == by_chr.end() || it->first != key) continue;
+                    const long long len = (long long)(offs[r + 1] - offs[r]);
+                    for (size_t fi : it->second) {
+                        const Feature& ft = feats[fi];
+                        long long s = ft.start, e = ft.end;                   // subseq.go:379-420, 471-512
+                        const bool minus = ft.strand == "-";
+                        if (minus) {
+                            if (o.only_flank) {
+                                if (o.up_stream > 0) { s = ft.end + 1; e = ft.end + o.up_stream; }
+                                else { s = ft.start - o.down_stream; e = ft.start - 1; }
+                            } else { s = ft.start - o.down_stream; e = ft.end + o.up_stream; }
+                        } else {
+                            if (o.only_flank) {
+                                if (o.up_stream > 0) { s = ft.start - o.up_stream; e = ft.start - 1; }
+                                else { s = e + 1; e = e + o.down_stream; }
+                            } else { s = ft.start - o.up_stream; e = ft.end + o.down_stream; }
+                        }
+                        if (s < 1) s = 1;
+                        if (e > len) e = len;
+                        skh_slice sl;
+                        sl.record = r; sl.start = s; sl.end = e; sl.minus = minus ? 1 : 0; sl.reserved = 0;
+                        slices.push_back(sl);
+                        out_npos.push_back(names.size());
+                        names += id; names += '_'; names += std::to_string(ft.start); names += '-';
+                        names += std::to_string(ft.end); names += ':'; names += ft.strand.empty() ? "." : ft.strand;
+                        names += flank; names += ' '; names += ft.label;
+                        out_nlen.push_back((uint32_t)(names.size() - out_npos.back()));
+                    }
+                }
+                if (slices.empty()) { tb.advance(res); continue; }
+                PhaseTimer pt(2);
+                if (skh_text_subseq(ctx.c, t, slices.data(), slices.size(), 0, 0, 0, lut, (const uint8_t*)names.data(),
+                                    names.size(), out_npos.data(), out_nlen.data()) != SKH_OK)
+                    return fatal(skh_last_error());
+                f.print_qual = 0; f.mark = '>';                               // fastx.NewRecord without qualities
+            } else {
+                tb.advance(res);                                              // no selection: nothing is printed
+                continue;
+            }
+            const uint8_t* text = nullptr;
+            uint64_t nbytes = 0;
+            {
+                PhaseTimer pt(3);
+                if (skh_text_format_seq(ctx.c, t, &f, &text, &nbytes) != SKH_OK) return fatal(skh_last_error());
+            }
+            { PhaseTimer pt(4); out.write(text, nbytes); }
+            tb.advance(res);
+        }
+        if (!tb.error().empty()) return fatal(tb.error());
+    }
+    return 0;
+}
+
 }  // namespace host

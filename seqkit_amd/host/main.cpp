@@ -1,6 +1,6 @@
-// main.cpp -- `seqkit-hip seq|fx2tab|stats [flags] [files...]`: command line of the three
+// main.cpp -- `seqkit-hip seq|fx2tab|stats|subseq [flags] [files...]`: command line of the
 // reference commands on the hot path (flag names and letters as registered in
-// seqkit/cmd/root.go:65-72, seq.go:291-306, fx2tab.go:157-164, stat.go:292-294).
+// seqkit/cmd/root.go:65-72, seq.go:291-306, fx2tab.go:157-164, stat.go:292-294, subseq.go:549-564).
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -90,7 +90,9 @@ int usage()
             "seqkit-hip -- SeqKit's seq / fx2tab / stats with the per-record work on an AMD MI355X\n\n"
             "Usage:\n  seqkit-hip seq    [-r] [-p] [-n] [-s] [-q] [-i] [-m N] [-M N] [global flags] [files...]\n"
             "  seqkit-hip fx2tab [-l] [-g] [-G] [-B bases]... [-n] [-i] [-H] [-a] [global flags] [files...]\n"
-            "  seqkit-hip stats  [-a] [-T] [-G gap-letters] [global flags] [files...]\n\n"
+            "  seqkit-hip stats  [-a] [-T] [-G gap-letters] [global flags] [files...]\n"
+            "  seqkit-hip subseq [-r start:end | --gtf FILE | --bed FILE] [--chr IDs] [--feature types] [--gtf-tag TAG]\n"
+            "                    [-u N] [-d N] [-f] [global flags] [files...]\n\n"
             "Global flags: -t/--seq-type dna|rna|protein|unlimit|auto, -j/--threads N, -w/--line-width N,\n"
             "  -o/--out-file FILE, --quiet, --alphabet-guess-seq-length N, --device N,\n"
             "  --batch-bytes N (text block / batch size), --host-parse (scan and print records on the host)\n");
@@ -103,8 +105,9 @@ int main(int argc, char** argv)
 {
     if (argc < 2) return usage();
     const std::string cmd = argv[1];
-    const bool is_seq = cmd == "seq", is_fx = cmd == "fx2tab", is_st = cmd == "stats" || cmd == "stat";
-    if (!is_seq && !is_fx && !is_st) return usage();
+    const bool is_seq = cmd == "seq", is_fx = cmd == "fx2tab", is_st = cmd == "stats" || cmd == "stat",
+               is_sub = cmd == "subseq";
+    if (!is_seq && !is_fx && !is_st && !is_sub) return usage();
 
     Parser p;
     p.flags = {{"t", "seq-type", true}, {"j", "threads", true}, {"w", "line-width", true}, {"o", "out-file", true},
@@ -116,6 +119,11 @@ int main(int argc, char** argv)
                           {"q", "qual", false}, {"i", "only-id", false}, {"m", "min-len", true}, {"M", "max-len", true},
                           {"v", "validate-seq", false}, {"V", "validate-seq-length", true}};
         p.flags.insert(p.flags.end(), f, f + 10);
+    } else if (is_sub) {
+        const Flag f[] = {{"r", "region", true}, {nullptr, "gtf", true}, {nullptr, "bed", true}, {nullptr, "gtf-tag", true},
+                          {nullptr, "chr", true}, {nullptr, "feature", true}, {"u", "up-stream", true},
+                          {"d", "down-stream", true}, {"f", "only-flank", false}};
+        p.flags.insert(p.flags.end(), f, f + 9);
     } else if (is_fx) {
         const Flag f[] = {{"l", "length", false}, {"g", "gc", false}, {"G", "gc-skew", false}, {"B", "base-content", true},
                           {"i", "only-id", false}, {"n", "name", false}, {"H", "header-line", false}, {"a", "alphabet", false}};
@@ -169,6 +177,18 @@ int main(int argc, char** argv)
             o.validate = true;
         }
         return cmd_seq(g, o, files);
+    }
+    if (is_sub) {
+        SubseqOpts o;
+        o.region = p.value("region", ""); o.gtf = p.value("gtf", ""); o.bed = p.value("bed", "");
+        o.gtf_tag = p.value("gtf-tag", "gene_id");
+        o.chr = p.values("chr"); o.feature = p.values("feature");
+        o.up_stream = atoi(p.value("up-stream", "0").c_str());
+        o.down_stream = atoi(p.value("down-stream", "0").c_str());
+        if (o.up_stream < 0) return fatal("value of flag --up-stream should be greater than 0");
+        if (o.down_stream < 0) return fatal("value of flag --down-stream should be greater than 0");
+        o.only_flank = p.has("only-flank");
+        return cmd_subseq(g, o, files);
     }
     if (is_fx) {
         Fx2tabOpts o;

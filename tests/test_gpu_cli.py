@@ -13,6 +13,7 @@ from conftest import GOLDEN, ROOT, check_vector, run_cli
 pytestmark = pytest.mark.gpu
 
 CLI = os.path.join(ROOT, "seqkit_amd", "seqkit-hip")
+GOLDEN_DIR = GOLDEN
 
 with open(os.path.join(GOLDEN, "expected", "manifest.json")) as _fh:
     _NAMES = sorted(json.load(_fh))
@@ -176,3 +177,87 @@ def test_long_records_through_the_driver(cli, oracle_cli, tmp_path):
         want = run_cli(oracle_cli, [a for a in argv if a not in ("--host-parse", "--batch-bytes", "65536")])
         got = run_cli(cli, argv)
         assert got[0] == want[0] == 0 and got[1] == want[1]
+
+
+# ---------------------------------------------------------------------------------------- subseq
+
+@pytest.mark.parametrize("f", FILES)
+@pytest.mark.parametrize("region", ["1:12", "-12:-1", "13:-13", "1:-1", "5:5", "200:100", "-3:-5", "30:1000000"])
+def test_subseq_region_matches_oracle(cli, oracle_cli, f, region):
+    want = run_cli(oracle_cli, ["subseq", "-r", region, f])
+    got = run_cli(cli, ["subseq", "-r", region, f])
+    assert got[0] == want[0] == 0 and got[1] == want[1]
+    got = run_cli(cli, ["subseq", "--batch-bytes", "4096", "-r", region, "-w", "7", f])      # many blocks per file
+    want = run_cli(oracle_cli, ["subseq", "-r", region, "-w", "7", f])
+    assert got[0] == 0 and got[1] == want[1]
+
+
+def test_subseq_region_errors(cli, oracle_cli):
+    for argv in (["subseq", "-r", "0:5"], ["subseq", "-r", "-3:4"], ["subseq", "-r", "abc"], ["subseq", "-r", "1:5", "-u", "3"],
+                 ["subseq", "--gtf", "subseq_test.gtf", "-f"], ["subseq", "--gtf", "subseq_test.gtf", "-f", "-u", "1", "-d", "1"]):
+        want = run_cli(oracle_cli, argv + ["contigs.fa"])
+        got = run_cli(cli, argv + ["contigs.fa"])
+        assert got[0] == want[0] == 255 and got[1] == want[1] == b"" and got[2] == want[2], argv
+
+
+def _feature_files(tmp_path, ids, rng, lengths):
+    gtf, bed = [], []
+    types = ["CDS", "exon", "gene"]
+    for k in range(400):
+        i = int(rng.integers(0, len(ids)))
+        a = int(rng.integers(1, max(lengths[i], 1) + 5))
+        b = a + int(rng.integers(1, 60))
+        strand = "+-."[int(rng.integers(0, 3))]
+        gtf.append("%s\tsrc\t%s\t%d\t%d\t.\t%s\t.\tgene_id \"g%d\"; transcript_id \"t%d\";\n"
+                   % (ids[i], types[k % 3], a, b, strand, k, k))
+        cols = [ids[i], str(a - 1), str(b)]
+        if k % 4:
+            cols.append("name%d" % k)
+            if k % 2:
+                cols += ["0", "+-"[k % 3 == 0]]
+        bed.append("\t".join(cols) + "\n")
+    g, b = tmp_path / "f.gtf", tmp_path / "f.bed"
+    g.write_text("# comment\n" + "".join(gtf)); b.write_text("track name=x\n" + "".join(bed))
+    return str(g), str(b)
+
+
+@pytest.mark.parametrize("f", ["hairpin.fa.gz", "reads_1.fq.gz", "contigs.fa"])
+def test_subseq_features_match_oracle(cli, oracle_cli, f, tmp_path):
+    import numpy as np
+    from helpers import read_fastx_plain
+    names, _, _, offs = read_fastx_plain(os.path.join(GOLDEN_DIR, f))
+    ids = [n.split()[0].decode() for n in names][:300]
+    lens = [int(offs[i + 1] - offs[i]) for i in range(len(ids))]
+    rng = np.random.default_rng(len(f))
+    gtf, bed = _feature_files(tmp_path, ids, rng, lens)
+    for flags in ([], ["-u", "3", "-d", "2"], ["-u", "100", "-d", "100"], ["-u", "5", "-f"], ["-d", "4", "-f"], ["-w", "11"]):
+        for sel in (["--gtf", gtf], ["--bed", bed], ["--gtf", gtf, "--feature", "cds,GENE"], ["--gtf", gtf, "--chr", ids[0] + "," + ids[5]],
+                    ["--gtf", gtf, "--gtf-tag", "transcript_id"]):
+            want = run_cli(oracle_cli, ["subseq"] + sel + flags + [f])
+            got = run_cli(cli, ["subseq"] + sel + flags + [f])
+            assert got[0] == want[0] == 0 and got[1] == want[1], (sel, flags)
+    got = run_cli(cli, ["subseq", "--batch-bytes", "4096", "--gtf", gtf, "-u", "7", f])
+    want = run_cli(oracle_cli, ["subseq", "--gtf", gtf, "-u", "7", f])
+    assert got[0] == 0 and got[1] == want[1]
+
+
+def test_subseq_long_overlapping_features(cli, oracle_cli, tmp_path):
+    import numpy as np
+    rng = np.random.default_rng(9)
+    fa = tmp_path / "chr.fa"
+    with open(fa, "wb") as fh:
+        for i, n in enumerate([300000, 1000, 120000]):
+            s = rng.choice(np.frombuffer(b"ACGTNacgtn", np.uint8), size=n).tobytes()
+            fh.write(b">chr%d some text\n" % i)
+            for a in range(0, n, 60):
+                fh.write(s[a:a + 60] + b"\n")
+    bed = tmp_path / "big.bed"
+    rows = []
+    for k in range(60):                                 # far more selected bases than the file holds
+        rows.append("chr%d\t%d\t%d\tf%d\t0\t%s\n" % (k % 3, k * 10, 100000 + k * 1000, k, "+-"[k & 1]))
+    bed.write_text("".join(rows))
+    want = run_cli(oracle_cli, ["subseq", "--bed", str(bed), str(fa)])
+    got = run_cli(cli, ["subseq", "--bed", str(bed), str(fa)])
+    assert got[0] == want[0] == 0 and got[1] == want[1]
+    got = run_cli(cli, ["subseq", "--bed", str(bed), "--batch-bytes", "65536", str(fa)])
+    assert got[0] == 0 and got[1] == want[1]

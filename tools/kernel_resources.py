@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""Prints VGPR/SGPR/scratch/LDS/occupancy per kernel of kernels.hip (hipcc remarks)."""
+"""Prints VGPR/SGPR/scratch/LDS/occupancy per kernel of a source under csrc/ (default kernels.hip; hipcc remarks)."""
 import os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(ROOT, "seqkit_amd", "csrc", "kernels.hip")
+src = os.path.join(ROOT, "seqkit_amd", "csrc", sys.argv[1] if len(sys.argv) > 1 else "kernels.hip")
 p = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-c",
                     "-I", os.path.join(ROOT, "include"), "-I", os.path.dirname(src),
                     "-Rpass-analysis=kernel-resource-usage", src, "-o", "/tmp/_kr.o"],

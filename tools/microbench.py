@@ -19,6 +19,17 @@ stats = torch.zeros(5, dtype=torch.int64, device=dev)
 lut = lib.pair_table(1); cls4 = lib.class_table(["G", "C", "A", "T"]); cls6 = lib.class_table(["G", "C", "A", "T", "N", "-"])
 gap = (C.c_uint8 * 256)(); gap[ord("-")] = 1
 valid = (C.c_uint8 * 256)(); lib.check(lib.skh_valid_table(1, valid))
+sub_offs = torch.empty(nrec + 1, dtype=torch.int64, device=dev)
+sub_wsb = lib.skh_subseq_workspace_size(nrec)
+sub_ws_t = torch.empty(sub_wsb + 256, dtype=torch.uint8, device=dev); sub_ws = (sub_ws_t.data_ptr() + 255) & ~255
+sub_res = torch.zeros(3, dtype=torch.int64, device=dev)
+
+
+def subseq(a, b, minus):
+    return lib.skh_subseq_dev(ctx, p(seq), None, p(offs), nrec, total, None, nrec, a, b, minus, lut, p(so), None, total,
+                              p(sub_offs), C.c_void_p(sub_ws), sub_wsb, p(sub_res), sp)
+
+
 torch.cuda.synchronize()   # data was generated on the default stream
 st = torch.cuda.Stream(device=dev); sp = C.c_void_p(st.cuda_stream)
 p = lambda t: C.c_void_p(t.data_ptr())
@@ -32,6 +43,9 @@ cases = {
     "count 4 classes (1B/base+40B/rec)": (lambda: lib.skh_count_dev(ctx, p(seq), p(offs), nrec, total, cls4, 4, p(counts), sp), total + 40 * nrec),
     "count 6 classes (1B/base+56B/rec)": (lambda: lib.skh_count_dev(ctx, p(seq), p(offs), nrec, total, cls6, 6, p(counts), sp), total + 56 * nrec),
     "validate DNAredundant, all bytes (1B/base)": (lambda: lib.skh_validate_dev(ctx, p(seq), p(offs), nrec, total, valid, 0, p(stats), sp), total),
+    "subseq -r 13:-13 (2B/out base+16B/rec)": (lambda: subseq(13, -13, 0), 2 * (L - 24) * nrec + 16 * nrec),
+    "subseq -r 1:-1 minus strand (2B/base+16B/rec)": (lambda: subseq(1, -1, 1), 2 * total + 16 * nrec),
+    "subseq -r 1:12 (2B/out base+16B/rec)": (lambda: subseq(1, 12, 0), 2 * 12 * nrec + 16 * nrec),
     "stats (1B/base+8B/rec)": (lambda: lib.skh_stats_dev(ctx, p(seq), p(offs), nrec, total, gap, p(stats), sp), total + 8 * nrec),
 }
 with torch.cuda.stream(st):
