@@ -1,7 +1,7 @@
 /*
  * oracle_cli.c -- TEST INFRASTRUCTURE ONLY (see seqkit_oracle.h).
  *
- * `seqkit_oracle seq|fx2tab|stats|subseq [flags] [files...]`: the reference commands
+ * `seqkit_oracle seq|fx2tab|stats|subseq|convert [flags] [files...]`: the reference commands
  * on the CPU restatement, with the reference's flag letters
  * (seqkit/cmd/seq.go:291-306, fx2tab.go:157-164, stat.go:292-294, subseq.go:549-564,
  * root.go:65-72).
@@ -16,7 +16,7 @@
 
 static int usage(void)
 {
-    fprintf(stderr, "usage: seqkit_oracle seq|fx2tab|stats|subseq [flags] [files...]\n");
+    fprintf(stderr, "usage: seqkit_oracle seq|fx2tab|stats|subseq|convert [flags] [files...]\n");
     return 255;
 }
 
@@ -41,14 +41,17 @@ int main(int argc, char **argv)
     static const char *chrs[256], *feats[256];
     const char *outfile = "-";
     int is_seq = !strcmp(cmd, "seq"), is_fx = !strcmp(cmd, "fx2tab"),
-        is_st = !strcmp(cmd, "stats") || !strcmp(cmd, "stat"), is_sub = !strcmp(cmd, "subseq");
-    if (!is_seq && !is_fx && !is_st && !is_sub) return usage();
+        is_st = !strcmp(cmd, "stats") || !strcmp(cmd, "stat"), is_sub = !strcmp(cmd, "subseq"),
+        is_cv = !strcmp(cmd, "convert");
+    ora_convert_opts co = {0}; co.to = ORA_Q_SANGER; co.nrecords = 1000; co.n_most_common = 4; co.illumina15_frac = 0.1;
+    co.guess_len = 10000;
+    if (!is_seq && !is_fx && !is_st && !is_sub && !is_cv) return usage();
 
     for (int i = 2; i < argc; i++) {
         const char *a = argv[i];
         if (a[0] != '-' || !strcmp(a, "-")) { if (nfiles < 1024) files[nfiles++] = a; continue; }
         /* bundled short bool flags, e.g. -rp or -nlg */
-        if (!is_sub && a[1] != '-' && strlen(a) > 2) {
+        if (!is_sub && !is_cv && a[1] != '-' && strlen(a) > 2) {
             int all_bool = 1;
             for (const char *p = a + 1; *p; p++) if (!strchr("rpnsqilgGHaT", *p)) all_bool = 0;
             if (all_bool && !(is_st && strchr(a, 'G')) && !(is_seq && strchr(a, 'G'))) {
@@ -105,6 +108,22 @@ int main(int argc, char **argv)
             if (is_flag(a, "-V", "--validate-seq-length")) { so.validate_len = (size_t)atoll(NEXT()); continue; }
             if (is_flag(a, "-m", "--min-len")) { so.min_len = atoi(NEXT()); continue; }
             if (is_flag(a, "-M", "--max-len")) { so.max_len = atoi(NEXT()); continue; }
+        } else if (is_cv) {
+            if (is_flag(a, NULL, "--from") || is_flag(a, NULL, "--to")) {
+                const int is_from = a[2] == 'f';
+                const char *v = NEXT();
+                int e = !strcasecmp(v, "sanger") ? ORA_Q_SANGER : !strcasecmp(v, "solexa") ? ORA_Q_SOLEXA
+                      : !strcasecmp(v, "illumina-1.3+") ? ORA_Q_ILLUMINA13 : !strcasecmp(v, "illumina-1.5+") ? ORA_Q_ILLUMINA15
+                      : !strcasecmp(v, "illumina-1.8+") ? ORA_Q_ILLUMINA18 : !strcmp(v, "") ? ORA_Q_UNKNOWN : -1;
+                if (e < 0) { fprintf(stderr, "[ERRO] unsupported quality encoding: %s\n", v); return 255; }
+                if (is_from) co.from = e; else co.to = e;
+                continue;
+            }
+            if (is_flag(a, "-d", "--dry-run")) { co.dry_run = 1; continue; }
+            if (is_flag(a, "-f", "--force")) { co.force = 1; continue; }
+            if (is_flag(a, "-n", "--nrecords")) { co.nrecords = atoi(NEXT()); continue; }
+            if (is_flag(a, "-N", "--thresh-B-in-n-most-common")) { co.n_most_common = atoi(NEXT()); continue; }
+            if (is_flag(a, "-F", "--thresh-illumina1.5-frac")) { co.illumina15_frac = atof(NEXT()); continue; }
         } else if (is_sub) {
             if (is_flag(a, "-r", "--region")) { uo.region = NEXT(); continue; }
             if (is_flag(a, NULL, "--gtf")) { uo.gtf = NEXT(); continue; }
@@ -154,6 +173,7 @@ int main(int argc, char **argv)
     int rc = is_seq ? ora_cmd_seq(&so, nfiles, files, out, stderr)
            : is_fx  ? ora_cmd_fx2tab(&fo, nfiles, files, out, stderr)
            : is_sub ? ora_cmd_subseq(&uo, nfiles, files, out, stderr)
+           : is_cv  ? ora_cmd_convert(&co, nfiles, files, out, stderr)
                     : ora_cmd_stats(&to, nfiles, files, out, stderr);
     if (out != stdout) fclose(out); else fflush(out);
     return rc;

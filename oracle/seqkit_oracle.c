@@ -964,3 +964,185 @@ int ora_cmd_subseq(const ora_subseq_opts *o, int nfiles, const char **files, FIL
     free(fs); free(types); free(wrapbuf); free(sub); free(name);
     return rcode;
 }
+
+/* ------------------------------------------------------------------ convert */
+const char *ora_quality_name(int enc)
+{
+    static const char *names[] = {"Unknown", "Sanger", "Solexa", "Illumina-1.3+", "Illumina-1.5+", "Illumina-1.8+"};
+    return enc >= 0 && enc < ORA_NQUAL ? names[enc] : "Unknown";
+}
+int ora_quality_offset(int enc) { return (enc == ORA_Q_SANGER || enc == ORA_Q_ILLUMINA18) ? 33 : 64; }
+int ora_quality_is_solexa(int enc) { return enc == ORA_Q_SOLEXA; }
+
+int ora_quality_table(int from, int to, int force, uint8_t lut[256], uint8_t valid[256])
+{
+    const int off_from = ora_quality_offset(from), off_to = ora_quality_offset(to);
+    const int sol_from = ora_quality_is_solexa(from), sol_to = ora_quality_is_solexa(to);
+    const int identity = from == to || (!force && off_from == 33 && off_to == 33);   /* Sanger <-> Illumina-1.8+ */
+    for (int c = 0; c < 256; c++) {
+        lut[c] = (uint8_t)c; valid[c] = 1;
+        if (identity) continue;
+        double q = (double)(c - off_from);
+        if (sol_from) {
+            if (q < -5) { valid[c] = 0; continue; }
+            if (!sol_to) q = 10.0 * log10(pow(10.0, q / 10.0) + 1.0);
+        } else {
+            if (q < 0) { valid[c] = 0; continue; }
+            if (from == ORA_Q_ILLUMINA15 && q <= 2) q = 0;       /* 'B': read segment quality control indicator */
+            if (sol_to) { q = q <= 0 ? -5.0 : 10.0 * log10(pow(10.0, q / 10.0) - 1.0); if (q < -5) q = -5; }
+        }
+        long r = (long)floor(q + 0.5);
+        if (to == ORA_Q_ILLUMINA15 && r < 2) r = 2;
+        if (force && to == ORA_Q_SANGER && r > 40) r = 40;   /* -f: "truncate scores > 40 to 40" */
+        lut[c] = (uint8_t)(r + off_to);
+    }
+    return identity;
+}
+
+unsigned ora_guess_quality_encoding(const uint8_t *qual, size_t n, int n_most_common)
+{
+    if (n == 0) return 0;
+    size_t cnt[256] = {0};
+    int mn = 255, mx = 0;
+    for (size_t i = 0; i < n; i++) { cnt[qual[i]]++; if (qual[i] < mn) mn = qual[i]; if (qual[i] > mx) mx = qual[i]; }
+    if (mn >= 66 && mx <= 105 && cnt['B'] > 0) {
+        int more = 0;                                   /* bytes strictly more frequent than 'B' */
+        for (int c = 0; c < 256; c++) if (cnt[c] > cnt['B']) more++;
+        if (more < n_most_common) return 1u << ORA_Q_ILLUMINA15;
+    }
+    unsigned set = 0;
+    if (mn >= 33 && mx <= 73) set |= 1u << ORA_Q_SANGER;
+    if (mn >= 59 && mx <= 104) set |= 1u << ORA_Q_SOLEXA;
+    if (mn >= 64 && mx <= 104) set |= 1u << ORA_Q_ILLUMINA13;
+    if (mn >= 66 && mx <= 105) set |= 1u << ORA_Q_ILLUMINA15;
+    if (mn >= 33 && mx <= 74) set |= 1u << ORA_Q_ILLUMINA18;
+    return set;
+}
+
+/* convert.go:100-152 / 185-238: the source encoding from the marks of the leading records.
+ * Returns the encoding, or -1 after printing the reference's error. */
+static int decide_encoding(const int marks[ORA_NQUAL], int n, int nrecords, double frac, FILE *err)
+{
+    int guessed[ORA_NQUAL], ng = 0;
+    for (int e = 0; e < ORA_NQUAL; e++) if (marks[e] == n) guessed[ng++] = e;
+    if ((double)(marks[ORA_Q_ILLUMINA15] / (nrecords + 1)) > frac) { guessed[0] = ORA_Q_ILLUMINA15; ng = 1; }  /* integer division, as written */
+    fprintf(err, "[INFO] possible quality encodings: [");
+    for (int i = 0; i < ng; i++) fprintf(err, "%s%s", i ? " " : "", ora_quality_name(guessed[i]));
+    fprintf(err, "]\n");
+    int from;
+    if (ng == 0) { fprintf(err, "[ERRO] quality encoding not consistent\n"); return -1; }
+    if (ng == 1) from = guessed[0];
+    else {
+        for (int i = 1; i < ng; i++)
+            if (ora_quality_is_solexa(guessed[i]) != ora_quality_is_solexa(guessed[0]) ||
+                ora_quality_offset(guessed[i]) != ora_quality_offset(guessed[0])) {
+                fprintf(err, "[ERRO] fail to guess the source quality encoding, please specify it\n");
+                return -1;
+            }
+        from = guessed[ng - 1];
+        if (from == ORA_Q_ILLUMINA18) from = ORA_Q_SANGER;
+    }
+    fprintf(err, "[INFO] guessed quality encoding: %s\n", ora_quality_name(from));
+    return from;
+}
+
+static int encodings_match(int a, int b, int force)          /* convert.go:313-326 */
+{
+    if (a == b) return 1;
+    if (!force && ((a == ORA_Q_SANGER && b == ORA_Q_ILLUMINA18) || (a == ORA_Q_ILLUMINA18 && b == ORA_Q_SANGER))) return 1;
+    return 0;
+}
+
+typedef struct kept { uint8_t *name, *seq, *qual; size_t nl, sl; } kept;
+
+static int convert_write(FILE *out, FILE *err, int from, const uint8_t lut[256], const uint8_t valid[256],
+                         const uint8_t *name, size_t nl, const uint8_t *seq, uint8_t *qual, size_t sl)
+{
+    for (size_t i = 0; i < sl; i++) {
+        if (!valid[qual[i]]) {
+            fflush(out);
+            fprintf(err, "[ERRO] seq: invalid %s quality\n", ora_quality_is_solexa(from) ? "Solexa" : "Phred");
+            return 255;
+        }
+    }
+    for (size_t i = 0; i < sl; i++) qual[i] = lut[qual[i]];
+    if (sl > 0) {                                          /* Record.FormatToWriter, line width 0 */
+        fputc('@', out); fwrite(name, 1, nl, out); fputc('\n', out);
+        fwrite(seq, 1, sl, out); fputs("\n+\n", out); fwrite(qual, 1, sl, out); fputc('\n', out);
+    } else {
+        fputc('>', out); fwrite(name, 1, nl, out); fputs("\n\n", out);
+    }
+    return 0;
+}
+
+int ora_cmd_convert(const ora_convert_opts *o, int nfiles, const char **files, FILE *out, FILE *err)
+{
+    int guessing = o->from <= 0, from = o->from, n = 0, rcode = 0;
+    int marks[ORA_NQUAL] = {0};
+    kept *recs = NULL;
+    uint8_t lut[256], valid[256];
+    if (guessing) recs = (kept *)calloc((size_t)o->nrecords + 1, sizeof *recs);
+    else {
+        fprintf(err, "[INFO] converting %s -> %s\n", ora_quality_name(from), ora_quality_name(o->to));
+        ora_quality_table(from, o->to, o->force, lut, valid);
+    }
+    for (int f = 0; f < nfiles && rcode == 0; f++) {
+        ora_reader *r = ora_reader_open(files[f], -1, o->guess_len);
+        if (!r) { fprintf(err, "[ERRO] open %s: no such file or directory\n", files[f]); rcode = 255; break; }
+        int once = 1, rc, stop = 0;
+        ora_record rec;
+        while (!stop && rcode == 0) {
+            rc = ora_reader_next(r, &rec);
+            if (rc != 1) {
+                if (rc < 0) { fprintf(err, "[ERRO] error when parsing %s\n", files[f]); rcode = 255; break; }
+                if (guessing && n < o->nrecords) {         /* convert.go:99-165: fewer records than -n */
+                    from = decide_encoding(marks, n, o->nrecords, o->illumina15_frac, err);
+                    if (from < 0) { rcode = 255; break; }
+                    fprintf(err, "[INFO] converting %s -> %s\n", ora_quality_name(from), ora_quality_name(o->to));
+                    if (once && encodings_match(from, o->to, o->force)) { once = 0; fprintf(err, "[WARN] source and target quality encoding match.\n"); }
+                    if (!o->dry_run) {
+                        ora_quality_table(from, o->to, o->force, lut, valid);
+                        for (int i = 0; i < n && rcode == 0; i++)
+                            rcode = convert_write(out, err, from, lut, valid, recs[i].name, recs[i].nl, recs[i].seq, recs[i].qual, recs[i].sl);
+                    }
+                }
+                break;
+            }
+            if (!ora_reader_is_fastq(r)) { fprintf(err, "[ERRO] this command only works for FASTQ format\n"); rcode = 255; break; }
+            if (guessing) {
+                if (n <= o->nrecords) {                     /* keep a copy (record.Clone()) */
+                    kept *k = &recs[n];
+                    k->nl = rec.name_len; k->sl = rec.seq_len;
+                    k->name = (uint8_t *)malloc(k->nl + 1); memcpy(k->name, rec.name, k->nl);
+                    k->seq = (uint8_t *)malloc(k->sl + 1); memcpy(k->seq, rec.seq, k->sl);
+                    k->qual = (uint8_t *)malloc(k->sl + 1); memcpy(k->qual, rec.qual, rec.qual_len < k->sl ? rec.qual_len : k->sl);
+                }
+                if (n < o->nrecords) {
+                    unsigned set = ora_guess_quality_encoding(rec.qual, rec.qual_len, o->n_most_common);
+                    for (int e = 0; e < ORA_NQUAL; e++) if (set & (1u << e)) marks[e]++;
+                } else {                                    /* n == nrecords: convert.go:184-250 */
+                    from = decide_encoding(marks, n, o->nrecords, o->illumina15_frac, err);
+                    if (from < 0) { rcode = 255; break; }
+                    fprintf(err, "[INFO] converting %s -> %s\n", ora_quality_name(from), ora_quality_name(o->to));
+                    if (once && encodings_match(from, o->to, o->force)) { once = 0; fprintf(err, "[WARN] source and target quality encoding match.\n"); }
+                    if (o->dry_run) { stop = 1; break; }
+                    ora_quality_table(from, o->to, o->force, lut, valid);
+                    for (int i = 0; i <= n && rcode == 0; i++)
+                        rcode = convert_write(out, err, from, lut, valid, recs[i].name, recs[i].nl, recs[i].seq, recs[i].qual, recs[i].sl);
+                    guessing = 0;
+                }
+                n++;
+                continue;
+            }
+            if (once && encodings_match(from, o->to, o->force)) { once = 0; fprintf(err, "[WARN] source and target quality encoding match.\n"); }
+            if (o->dry_run) break;
+            rcode = convert_write(out, err, from, lut, valid, rec.name, rec.name_len, rec.seq, rec.qual, rec.seq_len);
+        }
+        ora_reader_close(r);
+    }
+    if (recs) {
+        for (int i = 0; i <= o->nrecords; i++) { free(recs[i].name); free(recs[i].seq); free(recs[i].qual); }
+        free(recs);
+    }
+    return rcode;
+}

@@ -179,6 +179,39 @@ typedef struct ora_subseq_opts {
 } ora_subseq_opts;
 int ora_cmd_subseq(const ora_subseq_opts *o, int nfiles, const char **files, FILE *out, FILE *err);
 
+/* ---- convert (FASTQ quality re-encoding) ---- */
+/* bio/seq quality encodings (unpinned module; used at seqkit/cmd/convert.go:54-63,161,245,270). */
+enum { ORA_Q_UNKNOWN = 0, ORA_Q_SANGER = 1, ORA_Q_SOLEXA = 2, ORA_Q_ILLUMINA13 = 3, ORA_Q_ILLUMINA15 = 4,
+       ORA_Q_ILLUMINA18 = 5, ORA_NQUAL = 6 };
+const char *ora_quality_name(int enc);
+int ora_quality_offset(int enc);          /* 33 or 64 */
+int ora_quality_is_solexa(int enc);
+/* seq.QualityConvert as a byte table: lut[c] = converted byte, valid[c] = 0 where QualityConvert
+ * fails (score below the encoding's minimum: "seq: invalid Phred quality" / "seq: invalid Solexa
+ * quality").  Returns 1 when the conversion is the identity on every byte (from == to, or
+ * Sanger <-> Illumina-1.8+ without force).  Pinned by doc/docs/usage.md:878-956 (offset shifts
+ * 33 <-> 64, -f truncating 41 to 40, Illumina-1.5+ 'B' -> 0, Solexa rejecting low bytes); the
+ * Solexa <-> Phred score formula (Cock et al. 2010, rounded to nearest) and scores below 2 going
+ * to Illumina-1.5+ are parity unpinned. */
+int ora_quality_table(int from, int to, int force, uint8_t lut[256], uint8_t valid[256]);
+/* seq.GuessQualityEncoding: candidate encodings of one quality string as a bit set (1 << enc),
+ * by the byte range [min, max] against Sanger 33-73, Solexa 59-104, Illumina-1.3+ 64-104,
+ * Illumina-1.5+ 66-105, Illumina-1.8+ 33-74; Illumina-1.5+ alone when it fits and 'B' is among
+ * the `n_most_common` most frequent bytes.  Pinned only by the three documented guesses
+ * (usage.md:879, 924, 950); otherwise parity unpinned. */
+unsigned ora_guess_quality_encoding(const uint8_t *qual, size_t n, int n_most_common);
+
+typedef struct ora_convert_opts {
+    int from, to;               /* ORA_Q_*; from UNKNOWN = guess */
+    int dry_run, force;         /* -d -f */
+    int nrecords;               /* -n (default 1000) */
+    int n_most_common;          /* -N (default 4) */
+    double illumina15_frac;     /* -F (default 0.1) */
+    size_t guess_len;
+} ora_convert_opts;
+/* seqkit/cmd/convert.go:42-275 */
+int ora_cmd_convert(const ora_convert_opts *o, int nfiles, const char **files, FILE *out, FILE *err);
+
 #ifdef __cplusplus
 }
 #endif

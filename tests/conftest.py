@@ -88,6 +88,10 @@ def check_vector(cli, name, vec):
     assert rc == 0, err.decode()
     if mode == "exact":
         assert got == want
+    elif mode == "log+head4":
+        lines = want.splitlines(True)
+        log = b"".join(l for l in lines if l.startswith(b"["))
+        assert err == log and b"".join(got.splitlines(True)[:4]) == b"".join(l for l in lines if not l.startswith(b"["))
     elif mode == "head3":
         assert b"".join(got.splitlines(True)[:3]) == want
     elif mode == "fields4":

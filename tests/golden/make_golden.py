@@ -126,6 +126,31 @@ def subseq_vectors(ref, out_dir, manifest):
             None, "".join(md[r - 1].strip() + "\n" for r in rows), "documented GTF example, sequences only")
 
 
+def convert_vectors(ref, out_dir, manifest):
+    """convert known answers: the worked examples of doc/docs/usage.md:878-956.  Each block shows the
+    log lines on stderr ("[INFO] ...") followed by the first record (`| seqkit head -n 1`)."""
+    with open(os.path.join(ref, "doc/docs/usage.md"), encoding="utf-8") as fh:
+        md = fh.read().split("\n")
+    cases = [("G15_convert_default", 879, 886, ["convert", "Illimina1.8.fq.gz"], None),
+             ("G15_convert_force", 893, 899, ["convert", "Illimina1.8.fq.gz", "-f"], None),
+             ("G15_convert_to_illumina15", 908, 914, ["convert", "Illimina1.8.fq.gz", "--to", "Illumina-1.5+"], None),
+             # the second command's log lines and output; the first command's are the vector above
+             ("G15_convert_round_trip", 924, 930, ["convert", "Illimina1.8.fq.gz", "--to", "Illumina-1.5+"], ["convert"]),
+             ("G15_convert_illumina15_file", 950, 956, ["convert", "Illimina1.5.fq"], None)]
+    for name, a, b, argv, pipe in cases:
+        with open(os.path.join(out_dir, name + ".txt"), "w", encoding="utf-8") as fh:
+            fh.write("".join(l + "\n" for l in md[a - 1:b]))
+        manifest[name] = {"source": "doc/docs/usage.md:%d-%d" % (a, b), "argv": argv, "mode": "log+head4", "stdin": None,
+                          "note": "stderr lines, then the first record"}
+        if pipe:
+            manifest[name]["pipe"] = pipe
+    with open(os.path.join(out_dir, "G15_convert_from_solexa.txt"), "w", encoding="utf-8") as fh:
+        fh.write("".join(l + "\n" for l in md[936:938]))
+    manifest["G15_convert_from_solexa"] = {"source": "doc/docs/usage.md:937-938", "mode": "stderr255", "stdin": None,
+                                           "argv": ["convert", "Illimina1.8.fq.gz", "--from", "Solexa"],
+                                           "note": "a byte below the Solexa minimum: both stderr lines, exit status 255"}
+
+
 def main(ref):
     out_dir = os.path.join(HERE, "expected")
     os.makedirs(out_dir, exist_ok=True)
@@ -150,6 +175,7 @@ def main(ref):
                                        "argv": ["fx2tab", "hairpin.fa.gz", "-n", "-l"], "stdin": None,
                                        "note": "record lengths in file order"}
     subseq_vectors(ref, out_dir, manifest)
+    convert_vectors(ref, out_dir, manifest)
     with open(os.path.join(out_dir, "manifest.json"), "w") as fh:
         json.dump(manifest, fh, indent=1, sort_keys=True)
     print("wrote %d vectors to %s" % (len(manifest), out_dir))
