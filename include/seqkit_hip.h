@@ -135,6 +135,23 @@ int skh_validate_dev(skh_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_offse
                      uint64_t total_bytes, const uint8_t valid[256], uint64_t limit,
                      skh_validate_result *d_out, void *stream);
 
+/* FASTQ quality re-encoding (`seqkit convert`): seq.QualityConvert(from, to, qual, force)
+ * (bio/seq; call sites seqkit/cmd/convert.go:161,245,270) is a per-byte function, so it is
+ * handed to the GPU as a 256-entry table: skh_quality_table fills lut (converted byte) and
+ * valid (0 where QualityConvert fails: a score below the source encoding's minimum, reported
+ * by the caller as "seq: invalid Phred quality" / "seq: invalid Solexa quality"); *identity
+ * (may be NULL) is set when nothing changes (from == to, or Sanger <-> Illumina-1.8+ without
+ * force, convert.go:313-326).  On the device: skh_validate_dev(d_qual, ..., valid, 0, ...)
+ * finds the first record QualityConvert would reject, skh_revcomp_dev(d_qual, d_qual_out, ...,
+ * lut, 0, ...) converts the plane.  Offsets: Sanger and Illumina-1.8+ 33, the others 64;
+ * Illumina-1.5+ scores <= 2 ('B') read as 0; force cuts scores above 40 going to Sanger. */
+#define SKH_Q_SANGER     1
+#define SKH_Q_SOLEXA     2
+#define SKH_Q_ILLUMINA13 3
+#define SKH_Q_ILLUMINA15 4
+#define SKH_Q_ILLUMINA18 5
+int skh_quality_table(int from, int to, int force, uint8_t lut[256], uint8_t valid[256], int *identity);
+
 /* Subsequences: what `seqkit subseq` does to a record (seqkit/cmd/subseq.go:352-355 for
  * -r, :378-420 for GTF features, :470-512 for BED features): record.Seq.SubSeq(start, end),
  * followed by RevComInplace() for a feature on the minus strand (subseq.go:399,491).  A slice
@@ -324,6 +341,13 @@ int skh_text_validate(skh_ctx *ctx, skh_text *t, const uint8_t valid[256], uint6
 int skh_text_truncate(skh_ctx *ctx, skh_text *t, uint64_t nrec);
 /* Where record `record`'s name lies in the block's text buffer. */
 int skh_text_name(skh_ctx *ctx, skh_text *t, uint64_t record, uint64_t *pos, uint32_t *len);
+/* Quality bytes [first_byte, first_byte+count) of a FASTQ block copied to host memory (e.g. the
+ * leading records, for the encoding guess of convert.go:177-183). */
+int skh_text_quality(skh_ctx *ctx, skh_text *t, uint64_t first_byte, uint64_t count, uint8_t *dst);
+/* skh_validate_dev on the block's quality plane (all bytes of every record); *out is host memory. */
+int skh_text_validate_quality(skh_ctx *ctx, skh_text *t, const uint8_t valid[256], skh_validate_result *out);
+/* The block's qualities looked up in lut (convert.go:270); bases are kept. */
+int skh_text_map_quality(skh_ctx *ctx, skh_text *t, const uint8_t lut[256]);
 /* name_pos / name_len of records [first, first+count) copied to host memory; the names
  * themselves lie in skh_text_buffer(). */
 int skh_text_names(skh_ctx *ctx, skh_text *t, uint64_t first, uint64_t count, uint64_t *pos, uint32_t *len);

@@ -92,6 +92,10 @@ SYMBOLS = {
     "skh_text_validate": (C.c_int, [vp, vp, u8p, C.c_uint64, C.POINTER(ValidateResult)]),
     "skh_text_truncate": (C.c_int, [vp, vp, C.c_uint64]),
     "skh_text_name": (C.c_int, [vp, vp, C.c_uint64, u64p, C.POINTER(C.c_uint32)]),
+    "skh_quality_table": (C.c_int, [C.c_int, C.c_int, C.c_int, u8p, u8p, C.POINTER(C.c_int)]),
+    "skh_text_quality": (C.c_int, [vp, vp, C.c_uint64, C.c_uint64, u8p]),
+    "skh_text_validate_quality": (C.c_int, [vp, vp, u8p, C.POINTER(ValidateResult)]),
+    "skh_text_map_quality": (C.c_int, [vp, vp, u8p]),
     "skh_subseq_workspace_size": (C.c_uint64, [C.c_uint64]),
     "skh_subseq_dev": (C.c_int, [vp, vp, vp, vp, C.c_uint64, C.c_uint64, vp, C.c_uint64, C.c_int64, C.c_int64, C.c_int,
                                  u8p, vp, vp, C.c_uint64, vp, vp, C.c_uint64, vp, vp]),

@@ -5,6 +5,7 @@
 #include "seqkit_hip.h"
 
 #include <hip/hip_runtime.h>
+#include <math.h>
 
 #include <atomic>
 #include <cstdio>
@@ -222,6 +223,41 @@ int skh_valid_table(int alphabet, uint8_t valid[256])
     }
     memset(valid, 0, 256);
     for (const char* p = members; *p; p++) valid[(uint8_t)*p] = 1;
+    return SKH_OK;
+}
+
+int skh_quality_table(int from, int to, int force, uint8_t lut[256], uint8_t valid[256], int* identity)
+{
+    if (!lut || !valid) return fail(SKH_EINVAL, "NULL argument");
+    if (from < SKH_Q_SANGER || from > SKH_Q_ILLUMINA18 || to < SKH_Q_SANGER || to > SKH_Q_ILLUMINA18)
+        return fail(SKH_EINVAL, "unknown quality encoding");
+    auto offset = [](int e) { return (e == SKH_Q_SANGER || e == SKH_Q_ILLUMINA18) ? 33 : 64; };
+    const int off_from = offset(from), off_to = offset(to);
+    const bool sol_from = from == SKH_Q_SOLEXA, sol_to = to == SKH_Q_SOLEXA;
+    // nothing changes between Sanger and Illumina-1.8+ unless scores above 40 are to be cut (force)
+    const bool same = from == to || (!force && off_from == 33 && off_to == 33);
+    if (identity) *identity = same ? 1 : 0;
+    for (int c = 0; c < 256; c++) {
+        lut[c] = (uint8_t)c;
+        valid[c] = 1;
+        if (same) continue;
+        double q = (double)(c - off_from);
+        if (sol_from) {
+            if (q < -5) { valid[c] = 0; continue; }                    // "seq: invalid Solexa quality"
+            if (!sol_to) q = 10.0 * log10(pow(10.0, q / 10.0) + 1.0);
+        } else {
+            if (q < 0) { valid[c] = 0; continue; }                     // "seq: invalid Phred quality"
+            if (from == SKH_Q_ILLUMINA15 && q <= 2) q = 0;             // 'B', the read segment quality control indicator
+            if (sol_to) {
+                q = q <= 0 ? -5.0 : 10.0 * log10(pow(10.0, q / 10.0) - 1.0);
+                if (q < -5) q = -5;
+            }
+        }
+        long r = (long)floor(q + 0.5);
+        if (to == SKH_Q_ILLUMINA15 && r < 2) r = 2;
+        if (force && to == SKH_Q_SANGER && r > 40) r = 40;
+        lut[c] = (uint8_t)(r + off_to);
+    }
     return SKH_OK;
 }
 
@@ -1027,6 +1063,47 @@ int skh_text_name(skh_ctx* ctx, skh_text* t, uint64_t record, uint64_t* pos, uin
     HIP_TRY(hipStreamSynchronize(t->stream));
     memcpy(pos, h, 8);
     memcpy(len, h + 8, 4);
+    return SKH_OK;
+}
+
+int skh_text_quality(skh_ctx* ctx, skh_text* t, uint64_t first_byte, uint64_t count, uint8_t* dst)
+{
+    if (!ctx || !t || (!dst && count)) return fail(SKH_EINVAL, "NULL argument");
+    if (!t->fastq) return fail(SKH_EINVAL, "a FASTA block has no qualities");
+    if (first_byte + count > t->seq_bytes) return fail(SKH_EINVAL, "byte range beyond the block's qualities");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpyAsync(dst, (t->transformed ? t->d_qual2 : t->d_qual) + first_byte, count, hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    return SKH_OK;
+}
+
+int skh_text_validate_quality(skh_ctx* ctx, skh_text* t, const uint8_t valid[256], skh_validate_result* out)
+{
+    if (!ctx || !t || !valid || !out) return fail(SKH_EINVAL, "NULL argument");
+    memset(out, 0, sizeof *out);
+    if (!t->fastq) return fail(SKH_EINVAL, "a FASTA block has no qualities");
+    if (t->nrec == 0) return SKH_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc = skh_validate_dev(ctx, t->transformed ? t->d_qual2 : t->d_qual, t->v_offs, t->nrec, t->seq_bytes, valid, 0,
+                              static_cast<skh_validate_result*>(t->d_res), t->stream);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(t->h_res, t->d_res, sizeof(skh_validate_result), hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    memcpy(out, t->h_res, sizeof *out);
+    return SKH_OK;
+}
+
+int skh_text_map_quality(skh_ctx* ctx, skh_text* t, const uint8_t lut[256])
+{
+    if (!ctx || !t || !lut) return fail(SKH_EINVAL, "NULL argument");
+    if (!t->fastq) return fail(SKH_EINVAL, "a FASTA block has no qualities");
+    if (t->transformed) return fail(SKH_EINVAL, "block was already transformed");
+    if (t->nrec == 0) return SKH_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc = skh_revcomp_dev(ctx, t->d_qual, t->d_qual2, t->d_offs, t->nrec, t->seq_bytes, lut, 0, t->stream);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(t->d_seq2, t->d_seq, t->seq_bytes, hipMemcpyDeviceToDevice, t->stream));
+    t->transformed = true;
     return SKH_OK;
 }
 

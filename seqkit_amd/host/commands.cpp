@@ -134,6 +134,20 @@ public:
             return res.nrec != 0 || !done_;
         }
     }
+    bool at_eof() const { return eof_; }
+    // Instead of advance(): the block just parsed is given up and the next call of next() parses a
+    // block twice as large that starts at the same place (for callers that need more records at once).
+    bool grow()
+    {
+        skh_text* bigger = nullptr;
+        if (skh_text_alloc(ctx_, skh_text_capacity(t_) * 2, &bigger) != SKH_OK) { err_ = skh_last_error(); return false; }
+        memcpy(skh_text_buffer(bigger), skh_text_buffer(t_), have_);
+        skh_text_free(t_);
+        t_ = bigger;
+        consumed_ = 0;
+        done_ = false;
+        return true;
+    }
     // Call after the block has been used: keeps its unconsumed tail for the next one.
     void advance(const skh_parse_result& res)
     {
@@ -999,6 +1013,166 @@ int cmd_subseq(const GlobalOpts& g, const SubseqOpts& o, const std::vector<std::
             { PhaseTimer pt(4); out.write(text, nbytes); }
             tb.advance(res);
         }
+        if (!tb.error().empty()) return fatal(tb.error());
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------ convert
+namespace {
+
+const char* quality_name(int e)
+{
+    static const char* names[] = {"Unknown", "Sanger", "Solexa", "Illumina-1.3+", "Illumina-1.5+", "Illumina-1.8+"};
+    return e >= 0 && e < 6 ? names[e] : "Unknown";
+}
+int quality_offset(int e) { return (e == SKH_Q_SANGER || e == SKH_Q_ILLUMINA18) ? 33 : 64; }
+
+// seq.GuessQualityEncoding: the encodings whose byte range holds the string, as a bit set; only
+// Illumina-1.5+ when it fits and 'B' is among the n_most_common most frequent bytes
+unsigned guess_quality_encoding(const uint8_t* q, size_t n, int n_most_common)
+{
+    if (n == 0) return 0;
+    size_t cnt[256] = {0};
+    int mn = 255, mx = 0;
+    for (size_t i = 0; i < n; i++) { cnt[q[i]]++; mn = std::min<int>(mn, q[i]); mx = std::max<int>(mx, q[i]); }
+    const bool fits15 = mn >= 66 && mx <= 105;
+    if (fits15 && cnt['B'] > 0) {
+        int more = 0;
+        for (int c = 0; c < 256; c++) if (cnt[c] > cnt['B']) more++;
+        if (more < n_most_common) return 1u << SKH_Q_ILLUMINA15;
+    }
+    unsigned set = 0;
+    if (mn >= 33 && mx <= 73) set |= 1u << SKH_Q_SANGER;
+    if (mn >= 59 && mx <= 104) set |= 1u << SKH_Q_SOLEXA;
+    if (mn >= 64 && mx <= 104) set |= 1u << SKH_Q_ILLUMINA13;
+    if (fits15) set |= 1u << SKH_Q_ILLUMINA15;
+    if (mn >= 33 && mx <= 74) set |= 1u << SKH_Q_ILLUMINA18;
+    return set;
+}
+
+// convert.go:100-139 / 185-225: the source encoding from the marks of the n leading records; 0 on error
+int decide_encoding(const int marks[6], int n, int nrecords, double frac, std::string& err)
+{
+    std::vector<int> guessed;
+    for (int e = 0; e < 6; e++) if (marks[e] == n) guessed.push_back(e);
+    if ((double)(marks[SKH_Q_ILLUMINA15] / (nrecords + 1)) > frac) guessed.assign(1, SKH_Q_ILLUMINA15);   // integer division, as written
+    std::string list;
+    for (size_t i = 0; i < guessed.size(); i++) { if (i) list += ' '; list += quality_name(guessed[i]); }
+    fprintf(stderr, "[INFO] possible quality encodings: [%s]\n", list.c_str());
+    if (guessed.empty()) { err = "quality encoding not consistent"; return 0; }
+    int from = guessed[0];
+    if (guessed.size() > 1) {
+        for (size_t i = 1; i < guessed.size(); i++)
+            if ((guessed[i] == SKH_Q_SOLEXA) != (guessed[0] == SKH_Q_SOLEXA) || quality_offset(guessed[i]) != quality_offset(guessed[0])) {
+                err = "fail to guess the source quality encoding, please specify it";
+                return 0;
+            }
+        from = guessed.back();
+        if (from == SKH_Q_ILLUMINA18) from = SKH_Q_SANGER;
+    }
+    fprintf(stderr, "[INFO] guessed quality encoding: %s\n", quality_name(from));
+    return from;
+}
+
+bool encodings_match(int a, int b, bool force)                                  // convert.go:313-326
+{
+    if (a == b) return true;
+    return !force && ((a == SKH_Q_SANGER && b == SKH_Q_ILLUMINA18) || (a == SKH_Q_ILLUMINA18 && b == SKH_Q_SANGER));
+}
+
+}  // namespace
+
+// convert.go:42-275.  The source encoding is guessed from the first -n records of the input (the
+// first block is grown until it holds them), then every block's quality plane is checked and
+// looked up on the GPU and printed as FASTQ.  A file shorter than -n records is decided at its end,
+// as in the reference; unlike the reference, its records are not printed again with a later file.
+int cmd_convert(const GlobalOpts& g, const ConvertOpts& o, const std::vector<std::string>& files)
+{
+    if (g.host_parse) return fatal("convert has no --host-parse mode");
+    bool guessing = o.from <= 0;
+    int from = o.from, n = 0;
+    int marks[6] = {0, 0, 0, 0, 0, 0};
+    uint8_t lut[256], valid[256];
+    int identity = 0;
+    if (!guessing) {
+        fprintf(stderr, "[INFO] converting %s -> %s\n", quality_name(from), quality_name(o.to));
+        if (skh_quality_table(from, o.to, o.force, lut, valid, &identity) != SKH_OK) return fatal(skh_last_error());
+    }
+    Ctx ctx;
+    if (skh_init(g.device, &ctx.c) != SKH_OK) return fatal(skh_last_error());
+    Sink out(g.out_file);
+    if (!out.ok()) return fatal("open " + g.out_file + ": cannot create");
+    std::vector<uint64_t> offs;
+    std::vector<uint8_t> qual;
+    for (const std::string& file : files) {
+        TextBlocks tb(ctx.c, file, g.text_block_bytes);
+        if (!tb.ok()) return fatal(tb.error());
+        bool once = true;
+        std::string pending_error;
+        skh_parse_result res;
+        while (pending_error.empty() && tb.next(res)) {
+            skh_text* t = tb.block();
+            if (res.nrec == 0) { tb.advance(res); continue; }
+            if (!tb.is_fastq()) return fatal("this command only works for FASTQ format");
+            if (guessing) {
+                const uint64_t want = (uint64_t)(o.nrecords - n);           // records still to look at
+                if (res.nrec <= want && !tb.at_eof()) {
+                    // the decision needs more records than this block holds: a larger block
+                    // (records seen so far in it are looked at again)
+                    if (!tb.grow()) return fatal(tb.error());
+                    continue;
+                }
+                const uint64_t look = std::min<uint64_t>(res.nrec, want);
+                offs.resize(look + 1);
+                if (skh_text_offsets(ctx.c, t, 0, look + 1, offs.data()) != SKH_OK) return fatal(skh_last_error());
+                qual.resize(offs[look] ? offs[look] : 1);
+                if (offs[look] && skh_text_quality(ctx.c, t, 0, offs[look], qual.data()) != SKH_OK) return fatal(skh_last_error());
+                for (uint64_t r = 0; r < look; r++) {
+                    const unsigned set = guess_quality_encoding(qual.data() + offs[r], offs[r + 1] - offs[r], o.n_most_common);
+                    for (int e = 0; e < 6; e++) if (set & (1u << e)) marks[e]++;
+                }
+                n += (int)look;
+                std::string err;
+                from = decide_encoding(marks, n, o.nrecords, o.illumina15_frac, err);
+                if (from == 0) return fatal(err);
+                fprintf(stderr, "[INFO] converting %s -> %s\n", quality_name(from), quality_name(o.to));
+                if (skh_quality_table(from, o.to, o.force, lut, valid, &identity) != SKH_OK) return fatal(skh_last_error());
+                if (n >= o.nrecords) guessing = false;                     // else: decided at the end of a short file
+            }
+            if (once && encodings_match(from, o.to, o.force)) {
+                once = false;
+                fprintf(stderr, "[WARN] source and target quality encoding match.\n");
+            }
+            if (o.dry_run) break;
+            if (!identity) {
+                skh_validate_result vr;
+                if (skh_text_validate_quality(ctx.c, t, valid, &vr) != SKH_OK) return fatal(skh_last_error());
+                if (vr.found) {
+                    pending_error = std::string("seq: invalid ") + (from == SKH_Q_SOLEXA ? "Solexa" : "Phred") + " quality";
+                    if (skh_text_truncate(ctx.c, t, vr.record) != SKH_OK) return fatal(skh_last_error());
+                    res.nrec = vr.record;
+                    if (res.nrec == 0) break;
+                }
+                PhaseTimer pt(2);
+                if (skh_text_map_quality(ctx.c, t, lut) != SKH_OK) return fatal(skh_last_error());
+            }
+            skh_seq_format f;
+            memset(&f, 0, sizeof f);
+            f.min_len = f.max_len = -1;
+            f.line_width = 0;                                               // convert.go:171-172
+            f.print_name = 1; f.print_seq = 1; f.print_qual = 1; f.plus_line = 1; f.mark = '@';
+            f.empty_as_fasta = 1;                                           // Record.FormatToWriter: layout per record
+            const uint8_t* text = nullptr;
+            uint64_t nbytes = 0;
+            {
+                PhaseTimer pt(3);
+                if (skh_text_format_seq(ctx.c, t, &f, &text, &nbytes) != SKH_OK) return fatal(skh_last_error());
+            }
+            { PhaseTimer pt(4); out.write(text, nbytes); }
+            if (pending_error.empty()) tb.advance(res);
+        }
+        if (!pending_error.empty()) { out.flush(); return fatal(pending_error); }
         if (!tb.error().empty()) return fatal(tb.error());
     }
     return 0;

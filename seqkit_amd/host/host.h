@@ -1,6 +1,6 @@
 // host.h -- host side of the `seqkit-hip` driver: the SeqKit commands `seq`, `fx2tab`,
-// `stats` and `subseq` (flags as in the reference: seqkit/cmd/seq.go:291-306, fx2tab.go:157-164,
-// stat.go:292-294, subseq.go:549-564, root.go:65-72) with the per-record arithmetic replaced by batch calls
+// `stats`, `subseq` and `convert` (flags as in the reference: seqkit/cmd/seq.go:291-306, fx2tab.go:157-164,
+// stat.go:292-294, subseq.go:549-564, convert.go:280-291, root.go:65-72) with the per-record arithmetic replaced by batch calls
 // into libseqkit_hip.so.  The reader packs records into pinned CSR batches; the GPU does
 // reverse / complement / counting; everything textual (wrapping, %.2f, tables) is done here
 // from the integer results.
@@ -114,7 +114,11 @@ struct StatsOpts { bool all = false, tabular = false; std::string gap_letters = 
 struct SubseqOpts { std::string region, gtf, bed, gtf_tag = "gene_id"; std::vector<std::string> chr, feature;
                     int up_stream = 0, down_stream = 0; bool only_flank = false; };
 
+struct ConvertOpts { int from = 0, to = SKH_Q_SANGER; bool dry_run = false, force = false; int nrecords = 1000,
+                     n_most_common = 4; double illumina15_frac = 0.1; };
+
 int cmd_seq(const GlobalOpts& g, const SeqOpts& o, const std::vector<std::string>& files);
+int cmd_convert(const GlobalOpts& g, const ConvertOpts& o, const std::vector<std::string>& files);
 int cmd_subseq(const GlobalOpts& g, const SubseqOpts& o, const std::vector<std::string>& files);
 int cmd_fx2tab(const GlobalOpts& g, const Fx2tabOpts& o, const std::vector<std::string>& files);
 int cmd_stats(const GlobalOpts& g, const StatsOpts& o, const std::vector<std::string>& files);

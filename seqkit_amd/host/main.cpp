@@ -1,6 +1,7 @@
-// main.cpp -- `seqkit-hip seq|fx2tab|stats|subseq [flags] [files...]`: command line of the
+// main.cpp -- `seqkit-hip seq|fx2tab|stats|subseq|convert [flags] [files...]`: command line of the
 // reference commands on the hot path (flag names and letters as registered in
-// seqkit/cmd/root.go:65-72, seq.go:291-306, fx2tab.go:157-164, stat.go:292-294, subseq.go:549-564).
+// seqkit/cmd/root.go:65-72, seq.go:291-306, fx2tab.go:157-164, stat.go:292-294, subseq.go:549-564,
+// convert.go:280-291).
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -92,7 +93,8 @@ int usage()
             "  seqkit-hip fx2tab [-l] [-g] [-G] [-B bases]... [-n] [-i] [-H] [-a] [global flags] [files...]\n"
             "  seqkit-hip stats  [-a] [-T] [-G gap-letters] [global flags] [files...]\n"
             "  seqkit-hip subseq [-r start:end | --gtf FILE | --bed FILE] [--chr IDs] [--feature types] [--gtf-tag TAG]\n"
-            "                    [-u N] [-d N] [-f] [global flags] [files...]\n\n"
+            "                    [-u N] [-d N] [-f] [global flags] [files...]\n"
+            "  seqkit-hip convert [--from ENC] [--to ENC] [-f] [-d] [-n N] [-N N] [-F frac] [global flags] [files...]\n\n"
             "Global flags: -t/--seq-type dna|rna|protein|unlimit|auto, -j/--threads N, -w/--line-width N,\n"
             "  -o/--out-file FILE, --quiet, --alphabet-guess-seq-length N, --device N,\n"
             "  --batch-bytes N (text block / batch size), --host-parse (scan and print records on the host)\n");
@@ -106,8 +108,8 @@ int main(int argc, char** argv)
     if (argc < 2) return usage();
     const std::string cmd = argv[1];
     const bool is_seq = cmd == "seq", is_fx = cmd == "fx2tab", is_st = cmd == "stats" || cmd == "stat",
-               is_sub = cmd == "subseq";
-    if (!is_seq && !is_fx && !is_st && !is_sub) return usage();
+               is_sub = cmd == "subseq", is_cv = cmd == "convert";
+    if (!is_seq && !is_fx && !is_st && !is_sub && !is_cv) return usage();
 
     Parser p;
     p.flags = {{"t", "seq-type", true}, {"j", "threads", true}, {"w", "line-width", true}, {"o", "out-file", true},
@@ -119,6 +121,11 @@ int main(int argc, char** argv)
                           {"q", "qual", false}, {"i", "only-id", false}, {"m", "min-len", true}, {"M", "max-len", true},
                           {"v", "validate-seq", false}, {"V", "validate-seq-length", true}};
         p.flags.insert(p.flags.end(), f, f + 10);
+    } else if (is_cv) {
+        const Flag f[] = {{nullptr, "from", true}, {nullptr, "to", true}, {"d", "dry-run", false}, {"f", "force", false},
+                          {"n", "nrecords", true}, {"N", "thresh-B-in-n-most-common", true},
+                          {"F", "thresh-illumina1.5-frac", true}};
+        p.flags.insert(p.flags.end(), f, f + 7);
     } else if (is_sub) {
         const Flag f[] = {{"r", "region", true}, {nullptr, "gtf", true}, {nullptr, "bed", true}, {nullptr, "gtf-tag", true},
                           {nullptr, "chr", true}, {nullptr, "feature", true}, {"u", "up-stream", true},
@@ -177,6 +184,25 @@ int main(int argc, char** argv)
             o.validate = true;
         }
         return cmd_seq(g, o, files);
+    }
+    if (is_cv) {
+        ConvertOpts o;
+        auto encoding = [](std::string v) -> int {                          // convert.go:293-311
+            for (auto& ch : v) ch = (char)tolower((unsigned char)ch);
+            return v == "sanger" ? SKH_Q_SANGER : v == "solexa" ? SKH_Q_SOLEXA : v == "illumina-1.3+" ? SKH_Q_ILLUMINA13
+                 : v == "illumina-1.5+" ? SKH_Q_ILLUMINA15 : v == "illumina-1.8+" ? SKH_Q_ILLUMINA18 : v.empty() ? 0 : -1;
+        };
+        o.from = encoding(p.value("from", ""));
+        if (o.from < 0) return fatal("unsupported quality encoding: " + p.value("from", ""));
+        o.to = encoding(p.value("to", "Sanger"));
+        if (o.to < 0) return fatal("unsupported quality encoding: " + p.value("to", ""));
+        o.dry_run = p.has("dry-run"); o.force = p.has("force");
+        o.nrecords = atoi(p.value("nrecords", "1000").c_str());
+        if (o.nrecords <= 0) return fatal("value of flag --nrecords should be greater than 0");
+        o.n_most_common = atoi(p.value("thresh-B-in-n-most-common", "4").c_str());
+        if (o.n_most_common <= 0) return fatal("value of flag --thresh-B-in-n-most-common should be greater than 0");
+        o.illumina15_frac = atof(p.value("thresh-illumina1.5-frac", "0.1").c_str());
+        return cmd_convert(g, o, files);
     }
     if (is_sub) {
         SubseqOpts o;

@@ -261,3 +261,46 @@ def test_subseq_long_overlapping_features(cli, oracle_cli, tmp_path):
     assert got[0] == want[0] == 0 and got[1] == want[1]
     got = run_cli(cli, ["subseq", "--bed", str(bed), "--batch-bytes", "65536", str(fa)])
     assert got[0] == 0 and got[1] == want[1]
+
+
+# ---------------------------------------------------------------------------------------- convert
+
+ENCODINGS = ["Sanger", "Solexa", "Illumina-1.3+", "Illumina-1.5+", "Illumina-1.8+"]
+
+
+@pytest.mark.parametrize("f", ["Illimina1.8.fq.gz", "Illimina1.5.fq", "reads_1.fq.gz"])
+@pytest.mark.parametrize("to", ENCODINGS)
+def test_convert_guessed_matches_oracle(cli, oracle_cli, f, to):
+    for extra in ([], ["-f"], ["-n", "5"], ["-d"], ["--batch-bytes", "4096"]):
+        want = run_cli(oracle_cli, ["convert", "--to", to] + [a for a in extra if not a.startswith("--batch") and a != "4096"] + [f])
+        got = run_cli(cli, ["convert", "--to", to] + extra + [f])
+        assert got == want, (f, to, extra)
+
+
+@pytest.mark.parametrize("frm", ENCODINGS)
+@pytest.mark.parametrize("to", ENCODINGS)
+def test_convert_explicit_matches_oracle(cli, oracle_cli, frm, to):
+    # every byte value a quality line can hold, so that invalid scores and every table entry are met
+    import random
+    rnd = random.Random(len(frm) * 7 + len(to))
+    lo = 33 if frm in ("Sanger", "Illumina-1.8+") else (59 if frm == "Solexa" else 64)
+    recs = []
+    for i in range(300):
+        n = rnd.randint(0, 120)
+        q = "".join(chr(rnd.randint(lo, 126)) for _ in range(n))
+        if i == 250:
+            q = "!" * 5 + q                       # below the minimum of the 64-offset encodings
+            n += 5
+        recs.append("@r%d x\n%s\n+\n%s\n" % (i, "".join(rnd.choice("ACGTN") for _ in range(n)), q))
+    text = "".join(recs)
+    for extra in ([], ["-f"]):
+        want = run_cli(oracle_cli, ["convert", "--from", frm, "--to", to] + extra, stdin=text)
+        got = run_cli(cli, ["convert", "--from", frm, "--to", to] + extra, stdin=text)
+        assert got == want, (frm, to, extra)
+
+
+def test_convert_rejects_fasta(cli, oracle_cli):
+    want = run_cli(oracle_cli, ["convert", "contigs.fa"])
+    got = run_cli(cli, ["convert", "contigs.fa"])
+    assert got[0] == want[0] == 255 and got[1] == want[1] == b"" and got[2] == want[2]
+    assert run_cli(cli, ["convert", "--to", "phred", "reads_1.fq.gz"])[0] == 255
