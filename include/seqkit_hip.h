@@ -317,6 +317,12 @@ uint64_t skh_text_capacity(const skh_text *t);
  * A format error is reported in out->status, not in the return code. */
 int skh_text_parse(skh_ctx *ctx, skh_text *t, uint64_t text_bytes, int format, int final,
                    skh_parse_result *out);
+/* The same for text that starts text_offset bytes into the buffer (any offset): a reader that
+ * runs ahead of the parser fills a block from some headroom on and the unconsumed tail of the
+ * block before it is put in front afterwards.  skh_text_name(s) keep reporting positions in
+ * skh_text_buffer(). */
+int skh_text_parse_at(skh_ctx *ctx, skh_text *t, uint64_t text_offset, uint64_t text_bytes, int format,
+                      int final, skh_parse_result *out);
 /* Copies offsets[first .. first+count) of the parsed block to host memory. */
 int skh_text_offsets(skh_ctx *ctx, skh_text *t, uint64_t first, uint64_t count, uint64_t *offsets);
 /* Copies sequence bytes [first_byte, first_byte+count) of the block to host memory

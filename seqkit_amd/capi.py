@@ -107,6 +107,7 @@ SYMBOLS = {
     "skh_text_buffer": (vp, [vp]),
     "skh_text_capacity": (C.c_uint64, [vp]),
     "skh_text_parse": (C.c_int, [vp, vp, C.c_uint64, C.c_int, C.c_int, C.POINTER(ParseResult)]),
+    "skh_text_parse_at": (C.c_int, [vp, vp, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.POINTER(ParseResult)]),
     "skh_text_offsets": (C.c_int, [vp, vp, C.c_uint64, C.c_uint64, u64p]),
     "skh_text_sequence": (C.c_int, [vp, vp, C.c_uint64, C.c_uint64, u8p]),
     "skh_text_revcomp": (C.c_int, [vp, vp, u8p, C.c_int, C.c_int]),

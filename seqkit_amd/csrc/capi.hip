@@ -778,6 +778,7 @@ struct skh_text {
     // the block parsed last
     int fastq = 0;
     uint64_t nrec = 0, seq_bytes = 0, text_bytes = 0;
+    uint64_t text_off = 0;                  // where the parsed text starts in h_text (skh_text_parse_at)
     bool transformed = false;               // planes of the block now live in d_seq2 / d_qual2
     // what the later calls read: the parsed tables, or those of the slices after skh_text_subseq
     const uint64_t *v_offs = nullptr, *v_npos = nullptr;
@@ -882,10 +883,21 @@ uint64_t skh_text_capacity(const skh_text* t) { return t ? t->cap : 0; }
 
 int skh_text_parse(skh_ctx* ctx, skh_text* t, uint64_t text_bytes, int format, int final, skh_parse_result* out)
 {
+    return skh_text_parse_at(ctx, t, 0, text_bytes, format, final, out);
+}
+
+int skh_text_parse_at(skh_ctx* ctx, skh_text* t, uint64_t text_offset, uint64_t text_bytes, int format, int final,
+                      skh_parse_result* out)
+{
     if (!ctx || !t || !out) return fail(SKH_EINVAL, "NULL argument");
-    if (text_bytes > t->cap) return fail(SKH_ECAPACITY, "text block larger than its buffer");
+    if (text_offset > t->cap || text_bytes > t->cap - text_offset) return fail(SKH_ECAPACITY, "text block larger than its buffer");
     HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipMemcpyAsync(t->d_text, t->h_text, skh_padded_size(text_bytes), hipMemcpyHostToDevice, t->stream));
+    // the text goes to the start of the device buffer wherever it starts on the host; the bytes of the
+    // last, partial 16-byte chunk beyond text_bytes are never looked at by the parser
+    uint64_t up = skh_padded_size(text_bytes);
+    if (up > t->cap - text_offset) up = text_bytes;
+    if (up) HIP_TRY(hipMemcpyAsync(t->d_text, t->h_text + text_offset, up, hipMemcpyHostToDevice, t->stream));
+    t->text_off = text_offset;
     for (;;) {
         int rc = skh_parse_dev(ctx, t->d_text, text_bytes, format, final, t->d_seq, t->d_qual, t->cap, t->d_offs,
                                t->d_npos, t->d_nlen, t->max_lines, t->d_ws, t->ws_bytes, t->max_lines,
@@ -1063,6 +1075,7 @@ int skh_text_name(skh_ctx* ctx, skh_text* t, uint64_t record, uint64_t* pos, uin
     HIP_TRY(hipStreamSynchronize(t->stream));
     memcpy(pos, h, 8);
     memcpy(len, h + 8, 4);
+    if (t->v_text == t->d_text) *pos += t->text_off;       // positions in skh_text_buffer()
     return SKH_OK;
 }
 
@@ -1116,6 +1129,8 @@ int skh_text_names(skh_ctx* ctx, skh_text* t, uint64_t first, uint64_t count, ui
     HIP_TRY(hipMemcpyAsync(pos, t->v_npos + first, count * 8, hipMemcpyDeviceToHost, t->stream));
     HIP_TRY(hipMemcpyAsync(len, t->v_nlen + first, count * 4, hipMemcpyDeviceToHost, t->stream));
     HIP_TRY(hipStreamSynchronize(t->stream));
+    if (t->v_text == t->d_text && t->text_off)             // positions in skh_text_buffer()
+        for (uint64_t i = 0; i < count; i++) pos[i] += t->text_off;
     return SKH_OK;
 }
 

@@ -11,8 +11,13 @@
 
 #include <algorithm>
 #include <chrono>
+#include <atomic>
 #include <climits>
+#include <condition_variable>
 #include <cstring>
+#include <deque>
+#include <memory>
+#include <mutex>
 #include <thread>
 
 #include "host.h"
@@ -48,6 +53,40 @@ struct PhaseTimer {
     explicit PhaseTimer(int k_) : k(k_), t0(g_phases.on ? Phases::now() : 0) {}
     ~PhaseTimer() { if (g_phases.on) g_phases.t[k] += Phases::now() - t0; }
 };
+
+// Reads `want` bytes at `pos` of a regular file: the stretch is cut into equal parts read with
+// pread(2) by a few threads at once (one thread copies page-cache pages at 10-25 GB/s, a PCIe
+// link takes 50).  Returns the bytes read from `pos` on without a hole, or -1.
+long pread_parallel(int fd, uint8_t* dst, uint64_t want, uint64_t pos)
+{
+    unsigned nthr = std::thread::hardware_concurrency();
+    if (const char* e = getenv("SKH_READ_THREADS")) nthr = (unsigned)atoi(e);
+    if (nthr > 8) nthr = 8;
+    if (nthr < 1 || want < (8u << 20)) nthr = 1;
+    const uint64_t part = ((want + nthr - 1) / nthr + 4095) & ~uint64_t(4095);
+    std::vector<long> got(nthr, 0);
+    auto work = [&](unsigned k) {
+        uint64_t a = (uint64_t)k * part, b = a + part < want ? a + part : want;
+        while (a < b) {
+            const ssize_t n = pread(fd, dst + a, (size_t)(b - a), (off_t)(pos + a));
+            if (n < 0) { got[k] = -1; return; }
+            if (n == 0) break;                       // the end of the file
+            a += (uint64_t)n; got[k] += (long)n;
+        }
+    };
+    std::vector<std::thread> thr;
+    for (unsigned k = 1; k < nthr && (uint64_t)k * part < want; k++) thr.emplace_back(work, k);
+    work(0);
+    for (auto& t : thr) t.join();
+    long total = 0;
+    for (unsigned k = 0; k < nthr; k++) {
+        if (got[k] < 0) return -1;
+        total += got[k];
+        const uint64_t a = (uint64_t)k * part, b = a + part < want ? a + part : want;
+        if (a < want && (uint64_t)got[k] < b - a) break;    // short part: what follows it is not contiguous
+    }
+    return total;
+}
 
 // ---- file text in blocks, parsed on the GPU ------------------------------------------------
 //
@@ -164,40 +203,11 @@ public:
     }
 
 private:
-    // A regular file: the stretch [file_pos_, file_pos_ + want) is cut into equal parts read with pread(2)
-    // by a few threads at once (one thread copies page-cache pages at about 10 GB/s, a PCIe link takes 50).
     long read_regular(uint8_t* dst, uint64_t want)
     {
-        if (file_pos_ >= file_size_) return 0;
-        if (want > file_size_ - file_pos_) want = file_size_ - file_pos_;
-        unsigned nthr = std::thread::hardware_concurrency();
-        if (const char* e = getenv("SKH_READ_THREADS")) nthr = (unsigned)atoi(e);
-        if (nthr > 8) nthr = 8;
-        if (nthr < 1 || want < (8u << 20)) nthr = 1;
-        const uint64_t part = ((want + nthr - 1) / nthr + 4095) & ~uint64_t(4095);
-        std::vector<long> got(nthr, 0);
-        auto work = [&](unsigned k) {
-            uint64_t a = (uint64_t)k * part, b = a + part < want ? a + part : want;
-            while (a < b) {
-                const ssize_t n = pread(fd_, dst + a, (size_t)(b - a), (off_t)(file_pos_ + a));
-                if (n < 0) { got[k] = -1; return; }
-                if (n == 0) break;                       // the file shrank under us
-                a += (uint64_t)n; got[k] += (long)n;
-            }
-        };
-        std::vector<std::thread> thr;
-        for (unsigned k = 1; k < nthr && (uint64_t)k * part < want; k++) thr.emplace_back(work, k);
-        work(0);
-        for (auto& t : thr) t.join();
-        long total = 0;
-        for (unsigned k = 0; k < nthr; k++) {
-            if (got[k] < 0) return -1;
-            total += got[k];
-            const uint64_t a = (uint64_t)k * part, b = a + part < want ? a + part : want;
-            if (a < want && (uint64_t)got[k] < b - a) break;    // short part: what follows it is not contiguous
-        }
-        file_pos_ += (uint64_t)total;
-        return total;
+        const long n = pread_parallel(fd_, dst, want, file_pos_);
+        if (n > 0) file_pos_ += (uint64_t)n;
+        return n;
     }
 
     skh_ctx* ctx_; std::string path_, err_;
@@ -205,6 +215,248 @@ private:
     uint64_t file_size_ = UINT64_MAX, file_pos_ = 0;       // regular plain files only
     uint64_t have_ = 0, consumed_ = 0, lines_before_ = 0;
     bool eof_ = false, done_ = false, format_known_ = false, fastq_ = false, any_ = false;
+};
+
+// ---- the same, as a pipeline -----------------------------------------------------------------
+//
+// Three stages on three threads, a few text blocks going round: the READER fills a block's
+// pinned buffer from the file, starting `head` bytes in; the PARSER puts the unconsumed tail of
+// the block before in front of that (so a block never waits for its predecessor to be read),
+// uploads and parses it on the block's own stream; the CALLER (next / block / advance, as with
+// TextBlocks) runs kernels, formats, downloads and writes.  Block k+1 is read while block k is
+// uploaded and block k-1 is downloaded: the file system, the PCIe link in both directions and
+// the GPU work at once, and the slowest of them sets the pace.
+class BlockPipe {
+    struct Block {
+        skh_text* t = nullptr;
+        uint64_t cap = 0, head = 0;      // buffer size; where the reader starts to fill
+        uint64_t filled = 0;             // bytes the reader put at buffer + head
+        bool eof = false;                // the file ended in (or right after) this block
+        skh_parse_result res;
+    };
+    // a queue of block pointers; nullptr from pop() means "closed and empty"
+    struct Queue {
+        std::mutex mu; std::condition_variable cv; std::deque<Block*> q; bool closed = false;
+        void push(Block* b) { { std::lock_guard<std::mutex> l(mu); q.push_back(b); } cv.notify_all(); }
+        void close() { { std::lock_guard<std::mutex> l(mu); closed = true; } cv.notify_all(); }
+        Block* pop()
+        {
+            std::unique_lock<std::mutex> l(mu);
+            cv.wait(l, [&] { return !q.empty() || closed; });
+            if (q.empty()) return nullptr;
+            Block* b = q.front(); q.pop_front();
+            return b;
+        }
+    };
+    // everything the threads touch; outlives the object when the reader has to be left behind
+    struct State {
+        skh_ctx* ctx = nullptr; std::string path;
+        void* fh = nullptr; int fd = -1; uint64_t file_size = UINT64_MAX, file_pos = 0;
+        Queue free_q, filled_q, parsed_q;
+        std::vector<Block*> all;
+        std::mutex err_mu; std::string err;
+        std::atomic<bool> stop{false}, reader_done{false};
+        bool fastq = false;              // written by the parser before the first block is handed on
+        void fail(const std::string& m) { std::lock_guard<std::mutex> l(err_mu); if (err.empty()) err = m; }
+        std::string error() { std::lock_guard<std::mutex> l(err_mu); return err; }
+    };
+
+    static Block* new_block(State& s, uint64_t cap)
+    {
+        Block* b = new Block;
+        PhaseTimer pt(5);
+        if (skh_text_alloc(s.ctx, cap, &b->t) != SKH_OK) { s.fail(skh_last_error()); delete b; return nullptr; }
+        b->cap = skh_text_capacity(b->t);
+        b->head = (b->cap / 8) & ~uint64_t(4095);
+        return b;
+    }
+
+    static void reader(std::shared_ptr<State> sp)
+    {
+        State& s = *sp;
+        for (;;) {
+            Block* b = s.free_q.pop();
+            if (!b || s.stop) break;
+            uint8_t* buf = skh_text_buffer(b->t) + b->head;
+            const uint64_t room = b->cap - b->head;
+            b->filled = 0; b->eof = false;
+            bool bad = false;
+            while (b->filled < room && !b->eof && !s.stop) {
+                PhaseTimer pt(0);
+                const uint64_t want = room - b->filled > (1u << 30) ? (1u << 30) : room - b->filled;
+                long n;
+                if (s.fh) n = (long)gzread((gzFile)s.fh, buf + b->filled, (unsigned)want);
+                else if (s.file_size != UINT64_MAX) {
+                    n = pread_parallel(s.fd, buf + b->filled, want, s.file_pos);
+                    if (n > 0) s.file_pos += (uint64_t)n;
+                } else n = (long)read(s.fd, buf + b->filled, (size_t)want);
+                if (n < 0) { s.fail("read " + s.path + ": input error"); bad = true; break; }
+                if (n == 0) b->eof = true;
+                b->filled += (uint64_t)n;
+            }
+            if (bad || s.stop) break;
+            const bool last = b->eof;
+            s.filled_q.push(b);
+            if (last) break;
+        }
+        s.filled_q.close();
+        s.reader_done = true;
+    }
+
+    static void parser(std::shared_ptr<State> sp)
+    {
+        State& s = *sp;
+        std::vector<uint8_t> tail;       // text after the last complete record of the block before
+        bool format_known = false;
+        uint64_t lines_before = 0;
+        for (;;) {
+            Block* b = s.filled_q.pop();
+            if (!b || s.stop) break;
+            if (tail.size() > b->head) {
+                // the tail does not fit in front of what was read (a record longer than the headroom):
+                // both go into a block large enough for twice as much, which stays in the round
+                Block* nb = new_block(s, 2 * (tail.size() + b->cap));
+                if (!nb) break;
+                nb->head = tail.size();
+                memcpy(skh_text_buffer(nb->t) + nb->head, skh_text_buffer(b->t) + b->head, b->filled);
+                nb->filled = b->filled; nb->eof = b->eof;
+                for (auto& x : s.all) if (x == b) x = nb;
+                { PhaseTimer pt(5); skh_text_free(b->t); }
+                delete b;
+                b = nb;
+            }
+            uint8_t* buf = skh_text_buffer(b->t);
+            uint64_t off = b->head - tail.size(), have = tail.size() + b->filled;
+            if (!tail.empty()) memcpy(buf + off, tail.data(), tail.size());
+            b->head = (b->cap / 8) & ~uint64_t(4095);              // for its next round
+            tail.clear();
+            const bool eof = b->eof;
+            if (have == 0) {                                       // the file ended with the block before
+                if (eof) break;
+                s.free_q.push(b);
+                continue;
+            }
+            if (!format_known) {
+                uint64_t k = 0;
+                while (k < have && (buf[off + k] == '\n' || buf[off + k] == '\r')) k++;
+                off += k; have -= k;
+                if (have == 0) {                                   // blank lines only so far
+                    if (eof) break;
+                    s.free_q.push(b);
+                    continue;
+                }
+                if (buf[off] == '>') s.fastq = false;
+                else if (buf[off] == '@') s.fastq = true;
+                else { s.fail("error when parsing " + s.path + ": invalid FASTA/Q format"); break; }
+                format_known = true;
+            }
+            skh_parse_result res;
+            {
+                PhaseTimer pt(1);
+                if (skh_text_parse_at(s.ctx, b->t, off, have, s.fastq ? SKH_FASTQ : SKH_FASTA, eof, &res) != SKH_OK) {
+                    s.fail(skh_last_error());
+                    break;
+                }
+            }
+            if (res.status == SKH_PARSE_EFORMAT) {
+                s.fail("error when parsing " + s.path + ": invalid FASTA/Q format near line " +
+                       std::to_string(lines_before + (uint64_t)res.error_line + 1) +
+                       (s.fastq ? " (multi-line FASTQ needs --host-parse)" : ""));
+                break;
+            }
+            if (res.nrec == 0) res.consumed = 0;                   // nothing complete: all of it is tail
+            if (!eof) tail.assign(buf + off + res.consumed, buf + off + have);
+            lines_before += s.fastq ? res.nrec * 4 : res.lines;
+            if (res.nrec == 0) {
+                if (eof) break;
+                s.free_q.push(b);
+                continue;
+            }
+            b->res = res;
+            s.parsed_q.push(b);
+            if (eof) break;
+        }
+        s.stop = true;                   // nothing more will be parsed: the reader may stop too
+        s.free_q.close();
+        s.parsed_q.close();
+    }
+
+public:
+    BlockPipe(skh_ctx* ctx, const std::string& path, uint64_t block_bytes) : s_(std::make_shared<State>())
+    {
+        State& s = *s_;
+        s.ctx = ctx; s.path = path;
+        if (path != "-") {
+            s.fd = open(path.c_str(), O_RDONLY);
+            if (s.fd < 0) { s.err = "open " + path + ": no such file or directory"; return; }
+            struct stat st;
+            regular_ = fstat(s.fd, &st) == 0 && S_ISREG(st.st_mode);
+            unsigned char magic[2] = {0, 0};
+            const ssize_t got = pread(s.fd, magic, 2, 0);
+            if (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) { s.fh = gzdopen(s.fd, "rb"); s.fd = -1; }
+            else if (regular_) s.file_size = (uint64_t)st.st_size;
+        } else {
+            s.fh = gzdopen(0, "rb");
+        }
+        if (s.fd < 0 && !s.fh) { s.err = "open " + path + ": no such file or directory"; return; }
+        if (s.fh) gzbuffer((gzFile)s.fh, 1 << 20);
+        for (int k = 0; k < 3; k++) {
+            Block* b = new_block(s, block_bytes);
+            if (!b) return;
+            s.all.push_back(b);
+            s.free_q.push(b);
+        }
+        reader_ = std::thread(reader, s_);
+        parser_ = std::thread(parser, s_);
+    }
+    ~BlockPipe()
+    {
+        State& s = *s_;
+        s.stop = true;
+        s.free_q.close(); s.filled_q.close(); s.parsed_q.close();
+        if (parser_.joinable()) parser_.join();
+        bool leave = false;
+        if (reader_.joinable()) {
+            // a reader blocked on a pipe that stays silent cannot be woken: it is left behind with the
+            // state it uses (the process is on its way out when this happens)
+            if (regular_ || s.reader_done) reader_.join();
+            else { reader_.detach(); leave = true; }
+        }
+        if (leave) return;
+        PhaseTimer pt(5);
+        for (Block* b : s.all) { if (b->t) skh_text_free(b->t); delete b; }
+        s.all.clear();
+        if (s.fh) gzclose((gzFile)s.fh);
+        if (s.fd >= 0) close(s.fd);
+    }
+    BlockPipe(const BlockPipe&) = delete;
+    BlockPipe& operator=(const BlockPipe&) = delete;
+
+    bool ok() { return s_->error().empty(); }
+    std::string error() { return s_->error(); }
+    bool is_fastq() const { return s_->fastq; }
+    skh_text* block() const { return cur_ ? cur_->t : nullptr; }
+
+    // The next parsed block (at least one record), in file order.  false: end of the file or error.
+    bool next(skh_parse_result& res)
+    {
+        if (cur_) { s_->free_q.push(cur_); cur_ = nullptr; }
+        cur_ = s_->parsed_q.pop();
+        if (!cur_) return false;
+        res = cur_->res;
+        return true;
+    }
+    // The caller is done with the current block: it goes back to the reader.
+    void advance(const skh_parse_result&)
+    {
+        if (cur_) { s_->free_q.push(cur_); cur_ = nullptr; }
+    }
+
+private:
+    std::shared_ptr<State> s_;
+    std::thread reader_, parser_;
+    Block* cur_ = nullptr;
+    bool regular_ = false;
 };
 
 // alphabet of a file as the reference's reader guesses it: from the first record
@@ -226,7 +478,7 @@ int seq_text_path(const GlobalOpts& g, const SeqOpts& o, const std::vector<std::
     bool is_fastq = false, check_type = true;        // seq.go:105-106: decided once, by the first printed record
     std::vector<uint64_t> offs;
     for (const std::string& file : files) {
-        TextBlocks tb(ctx, file, g.text_block_bytes);
+        BlockPipe tb(ctx, file, g.text_block_bytes);
         if (!tb.ok()) return fatal(tb.error());
         uint8_t lut[256], valid[256];
         bool lut_ready = false;
@@ -497,7 +749,7 @@ int cmd_fx2tab(const GlobalOpts& g, const Fx2tabOpts& o, const std::vector<std::
     }
     if (device_rows) {
         for (const std::string& file : files) {
-            TextBlocks tb(ctx.c, file, g.text_block_bytes);
+            BlockPipe tb(ctx.c, file, g.text_block_bytes);
             if (!tb.ok()) return fatal(tb.error());
             skh_parse_result res;
             while (tb.next(res)) {
@@ -689,7 +941,7 @@ int cmd_stats(const GlobalOpts& g, const StatsOpts& o, const std::vector<std::st
     for (const std::string& file : files) {
         if (!g.host_parse) {
             // file text parsed on the GPU: per block the totals kernel, and for -a the lengths
-            TextBlocks tb(ctx.c, file, g.text_block_bytes);
+            BlockPipe tb(ctx.c, file, g.text_block_bytes);
             if (!tb.ok()) return fatal(tb.error());
             skh_stats_partial tot;
             skh_stats_init(&tot);

@@ -11,6 +11,7 @@ FA=/tmp/e2e.fa
 python3 tools/gen_fastx.py $FA $NREC $L 0xC3 --fasta --width 60
 ls -l $FQ $FA
 cat $FQ $FA > /dev/null
+./seqkit_amd/seqkit-hip stats $FA > /dev/null     # first GPU process on a fresh box pays for driver start-up
 t() { local s=$(date +%s.%N); "$@" > /dev/null; local e=$(date +%s.%N); echo "$s $e" | awk -v n=$NREC -v l=$L '{printf "%8.3f s  %8.3f Gbases/s", $2-$1, n*l/($2-$1)/1e9}'; }
 {
 echo "records $NREC x $L bp"
