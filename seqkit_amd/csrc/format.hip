@@ -6,10 +6,13 @@
 // for width < 1 or an empty sequence), and for FASTQ the "+" line and the quality string.
 // Three streaming passes: output size of every record, exclusive scan of the sizes, and a
 // cooperative copy (16 lanes per record, 16 bytes per lane and step) of names, bases and
-// qualities to their places in the output text.
+// qualities to their places in the output text.  Records longer than SKH_LONG_T leave their
+// bases and qualities to a second kernel whose workgroups own windows of the sequence plane, so
+// that a chromosome-length record is written by thousands of workgroups, not by 16 lanes.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "device_util.h"
 #include "kernels.h"
 
 namespace skh {
@@ -35,11 +38,12 @@ __device__ __forceinline__ uint32_t id_length(const uint8_t* __restrict__ name, 
 }
 
 __global__ __launch_bounds__(FB) void k_fmt_sizes(const FormatSeqArgs a, uint64_t* __restrict__ size,
-                                                  uint32_t* __restrict__ shown_name)
+                                                  uint32_t* __restrict__ shown_name, uint32_t* __restrict__ n_long)
 {
     for (uint64_t r = (uint64_t)blockIdx.x * FB + threadIdx.x; r < a.nrec; r += (uint64_t)gridDim.x * FB) {
         const uint64_t len = a.offsets[r + 1] - a.offsets[r];
         const bool keep = !(a.min_len >= 0 && len < (uint64_t)a.min_len) && !(a.max_len >= 0 && len > (uint64_t)a.max_len);
+        if (keep && len > SKH_LONG_T && (a.print_seq || a.print_qual)) atomicAdd(n_long, 1u);
         uint32_t nl = 0;
         uint64_t sz = 0;
         if (keep) {
@@ -170,17 +174,81 @@ __global__ __launch_bounds__(FB) void k_fmt_write(const FormatSeqArgs a, const u
             if (j == 0) o[nl] = '\n';
             o += nl + 1;
         }
+        const bool is_long = len > SKH_LONG_T;           // bases and qualities: k_fmt_write_long
         if (a.print_seq) {
-            copy_wrapped<G>(o, a.seq + s, len, a.width, j);
+            if (!is_long) copy_wrapped<G>(o, a.seq + s, len, a.width, j);
             const uint64_t w = wrapped_len(len, a.width);
             if (j == 0) o[w] = '\n';
             o += w + 1;
         }
         if (a.print_qual && !(a.empty_fasta && len == 0)) {
             if (a.plus_line) { if (j == 0) { o[0] = '+'; o[1] = '\n'; } o += 2; }
-            copy_wrapped<G>(o, a.qual + s, len, a.width, j);
+            if (!is_long) copy_wrapped<G>(o, a.qual + s, len, a.width, j);
             const uint64_t w = wrapped_len(len, a.width);
             if (j == 0) o[w] = '\n';
+        }
+    }
+}
+
+// Bases [k0, k1) of a record's sequence (or quality) string `src` to their places in the wrapped
+// text at `dst` (where base 0 goes), by the whole workgroup; the line break that follows base
+// b*width-1 is written by whoever writes that base.  n = length of the whole string.
+__device__ __forceinline__ void copy_wrapped_range(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, uint64_t n,
+                                                   uint32_t width, uint64_t k0, uint64_t k1)
+{
+    const bool wrap = width >= 1;
+    for (uint64_t p = k0 + 16ull * threadIdx.x; p < k1; p += 16ull * FB) {
+        const uint64_t last = p + 16 <= k1 ? p + 15 : k1 - 1;
+        const uint64_t l0 = wrap ? p / width : 0, l1 = wrap ? last / width : 0;
+        if (l0 == l1 && p + 16 <= k1) {
+            uint4 v;
+            __builtin_memcpy(&v, src + p, 16);
+            __builtin_memcpy(dst + p + l0, &v, 16);
+        } else {
+            for (uint64_t k = p; k <= last; k++) dst[k + (wrap ? k / width : 0)] = src[k];
+        }
+    }
+    if (wrap && n != 0) {
+        // break b (1-based) follows base b*width-1 and sits at dst[b*width + b - 1]
+        const uint64_t breaks = (n - 1) / width;
+        const uint64_t b0 = k0 / width + 1;                 // first b with b*width-1 >= k0
+        for (uint64_t b = b0 + threadIdx.x; b <= breaks && b * width - 1 < k1; b += FB) dst[b * width + b - 1] = '\n';
+    }
+}
+
+// Bases and qualities of the records longer than SKH_LONG_T.  Workgroups own aligned windows of
+// the sequence plane; only the records that hold a window's first and last byte can be long.
+__global__ __launch_bounds__(FB) void k_fmt_write_long(const FormatSeqArgs a, const uint64_t* __restrict__ size,
+                                                       const uint64_t* __restrict__ pos,
+                                                       const uint32_t* __restrict__ shown_name,
+                                                       const uint64_t* __restrict__ total, const uint32_t* __restrict__ n_long,
+                                                       uint8_t* __restrict__ out, uint64_t out_capacity)
+{
+    if (*n_long == 0 || *total > out_capacity) return;
+    const uint64_t plane = a.offsets[a.nrec];
+    const uint64_t ntiles = (plane + SKH_TILE - 1) / SKH_TILE;
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint64_t t0 = tile * SKH_TILE;
+        const uint64_t t1 = t0 + SKH_TILE < plane ? t0 + SKH_TILE : plane;
+        const uint64_t r_lo = find_record(a.offsets, a.nrec, t0);
+        const uint64_t r_hi = find_record(a.offsets, a.nrec, t1 - 1);
+#pragma unroll 1
+        for (int c = 0; c < 2; c++) {
+            if (c == 1 && r_hi == r_lo) break;
+            const uint64_t r = c == 0 ? r_lo : r_hi;
+            const uint64_t s = a.offsets[r], e = a.offsets[r + 1], len = e - s;
+            if (len <= SKH_LONG_T || size[r] == 0) continue;          // block-uniform
+            const uint64_t k0 = (s > t0 ? s : t0) - s, k1 = (e < t1 ? e : t1) - s;
+            uint8_t* o = out + pos[r];
+            if (a.print_name) o += (a.print_seq ? 1 : 0) + (uint64_t)shown_name[r] + 1;
+            if (a.print_seq) {
+                copy_wrapped_range(o, a.seq + s, len, a.width, k0, k1);
+                o += wrapped_len(len, a.width) + 1;
+            }
+            if (a.print_qual) {
+                if (a.plus_line) o += 2;
+                copy_wrapped_range(o, a.qual + s, len, a.width, k0, k1);
+            }
         }
     }
 }
@@ -303,10 +371,41 @@ __global__ __launch_bounds__(FB) void k_tab_write(const FormatTabArgs a, const u
         copy_plain<G>(o, a.text + a.name_pos[r], nl, j);
         if (j == 0) o[nl] = '\t';
         o += nl + 1;
-        if (a.print_seq) { copy_plain<G>(o, a.seq + s, len, j); o += len; }
+        const bool is_long = len > SKH_LONG_T;           // bases and qualities: k_tab_write_long
+        if (a.print_seq) { if (!is_long) copy_plain<G>(o, a.seq + s, len, j); o += len; }
         if (j == 0) *o = '\t';
         o++;
-        if (a.print_qual) { copy_plain<G>(o, a.qual + s, len, j); o += len; }
+        if (a.print_qual) { if (!is_long) copy_plain<G>(o, a.qual + s, len, j); o += len; }
+    }
+}
+
+// Sequence and quality fields of the rows of records longer than SKH_LONG_T (windows of the
+// sequence plane, as in k_fmt_write_long).
+__global__ __launch_bounds__(FB) void k_tab_write_long(const FormatTabArgs a, const uint64_t* __restrict__ pos,
+                                                       const uint32_t* __restrict__ shown_name,
+                                                       const uint64_t* __restrict__ total, uint8_t* __restrict__ out,
+                                                       uint64_t out_capacity)
+{
+    if (*total > out_capacity) return;
+    const uint64_t plane = a.offsets[a.nrec];
+    const uint64_t ntiles = (plane + SKH_TILE - 1) / SKH_TILE;
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint64_t t0 = tile * SKH_TILE;
+        const uint64_t t1 = t0 + SKH_TILE < plane ? t0 + SKH_TILE : plane;
+        const uint64_t r_lo = find_record(a.offsets, a.nrec, t0);
+        const uint64_t r_hi = find_record(a.offsets, a.nrec, t1 - 1);
+#pragma unroll 1
+        for (int c = 0; c < 2; c++) {
+            if (c == 1 && r_hi == r_lo) break;
+            const uint64_t r = c == 0 ? r_lo : r_hi;
+            const uint64_t s = a.offsets[r], e = a.offsets[r + 1], len = e - s;
+            if (len <= SKH_LONG_T) continue;                          // block-uniform
+            const uint64_t k0 = (s > t0 ? s : t0) - s, k1 = (e < t1 ? e : t1) - s;
+            uint8_t* o = out + pos[r] + shown_name[r] + 1;
+            if (a.print_seq) { copy_wrapped_range(o, a.seq + s, len, 0, k0, k1); o += len; }
+            o++;
+            if (a.print_qual) copy_wrapped_range(o, a.qual + s, len, 0, k0, k1);
+        }
     }
 }
 
@@ -367,12 +466,17 @@ hipError_t launch_format_seq(const FormatSeqArgs& a, uint8_t* out, uint64_t out_
     uint64_t* part = reinterpret_cast<uint64_t*>(ws);
     const uint64_t npart = (a.nrec + FSCAN_TILE - 1) / FSCAN_TILE ? (a.nrec + FSCAN_TILE - 1) / FSCAN_TILE : 1;
     auto capped = [](uint64_t b) { return (uint32_t)(b < 1 ? 1 : (b > 16384 ? 16384 : b)); };
-    hipLaunchKernelGGL(k_fmt_sizes, dim3(capped((a.nrec + FB - 1) / FB)), dim3(FB), 0, s, a, size, shown);
+    uint32_t* n_long = reinterpret_cast<uint32_t*>(total + 1);       // second word of the 256-byte head of the workspace
+    hipError_t e = hipMemsetAsync(total, 0, 16, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_fmt_sizes, dim3(capped((a.nrec + FB - 1) / FB)), dim3(FB), 0, s, a, size, shown, n_long);
     hipLaunchKernelGGL(k_scan_partials64, dim3((uint32_t)npart), dim3(FB), 0, s, size, a.nrec, part);
     hipLaunchKernelGGL(k_scan_top64, dim3(1), dim3(1024), 0, s, part, npart, total);
     hipLaunchKernelGGL(k_scan_apply64, dim3((uint32_t)npart), dim3(FB), 0, s, size, a.nrec, part, pos);
     hipLaunchKernelGGL(k_fmt_write, dim3(capped((a.nrec * 16 + FB - 1) / FB)), dim3(FB), 0, s, a, size, pos, shown, total,
                        out, out_capacity);
+    if (a.nrec != 0 && (a.print_seq || a.print_qual))
+        hipLaunchKernelGGL(k_fmt_write_long, dim3(2048), dim3(FB), 0, s, a, size, pos, shown, total, n_long, out, out_capacity);
     hipLaunchKernelGGL(k_fmt_finish, dim3(1), dim3(1), 0, s, total, out_capacity, res);
     return hipGetLastError();
 }
@@ -394,6 +498,8 @@ hipError_t launch_format_tab(const FormatTabArgs& a, uint8_t* out, uint64_t out_
     hipLaunchKernelGGL(k_scan_apply64, dim3((uint32_t)npart), dim3(FB), 0, s, size, a.nrec, part, pos);
     hipLaunchKernelGGL(k_tab_write, dim3(capped((a.nrec * 16 + FB - 1) / FB)), dim3(FB), 0, s, a, pos, shown, total, out,
                        out_capacity);
+    if (a.nrec != 0 && (a.print_seq || a.print_qual))
+        hipLaunchKernelGGL(k_tab_write_long, dim3(2048), dim3(FB), 0, s, a, pos, shown, total, out, out_capacity);
     hipLaunchKernelGGL(k_tab_numbers, dim3(capped((a.nrec + FB - 1) / FB)), dim3(FB), 0, s, a, pos, shown, total, out,
                        out_capacity);
     hipLaunchKernelGGL(k_fmt_finish, dim3(1), dim3(1), 0, s, total, out_capacity, res);

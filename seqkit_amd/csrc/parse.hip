@@ -34,6 +34,7 @@ namespace skh {
 namespace {
 
 constexpr int PB = 256;                      // threads per workgroup
+constexpr uint64_t LONG_LINE = 32768;         // lines longer than this are copied window-wise
 constexpr int NLU = 4;                       // 16-byte chunks per thread in the newline passes
 constexpr uint32_t TILE = PB * 16 * NLU;     // text bytes per workgroup in the newline passes
 
@@ -168,6 +169,8 @@ struct ParseState {            // device scratch shared by the passes of one cal
     unsigned long long first_blank_head;   // FASTQ: first blank line in a head position (min), ~0 = none
     uint32_t any_nonblank;
     uint32_t status;
+    uint32_t n_long;           // lines longer than LONG_LINE (copied window-wise)
+    uint32_t pad;
     LineSum total;             // totals of the line scan
     uint64_t nrec, seq_bytes, consumed;    // the decision
 };
@@ -184,6 +187,7 @@ __global__ void k_parse_init(ParseState* st, uint64_t n, int final, const uint8_
     st->last_nonblank = 0;
     st->first_blank_head = ~0ull;
     st->any_nonblank = 0;
+    st->n_long = 0;
     st->total.bytes = 0;
     st->total.heads = 0;
 }
@@ -238,6 +242,7 @@ __global__ __launch_bounds__(PB) void k_line_table(const uint8_t* __restrict__ t
             }                                            // role 3 (equal lengths) is checked by k_line_partials
         }
         if (len) { last = i; any = true; }            // i grows within a thread
+        if (len > LONG_LINE) atomicAdd(&st->n_long, 1u);
         if (bad && i < err) err = i;
         line_start[i] = ls;
         line_len[i] = len;
@@ -492,6 +497,7 @@ __global__ __launch_bounds__(PB) void k_parse_copy(const ParseState* st, uint64_
             dst = line_dst[i];
         }
         const uint32_t len = line_len[i];
+        if (len > LONG_LINE) continue;                   // k_parse_copy_long
         const uint8_t* src = text + line_start[i];
         uint8_t* out = dst_plane + dst;
         for (uint32_t p = j * 16; p < len; p += G * 16) {
@@ -501,6 +507,69 @@ __global__ __launch_bounds__(PB) void k_parse_copy(const ParseState* st, uint64_
                 __builtin_memcpy(out + p, &v, 16);
             } else {
                 for (uint32_t k = p; k < len; k++) out[k] = src[k];
+            }
+        }
+    }
+}
+
+// The lines longer than LONG_LINE (unwrapped chromosome-length sequences): workgroups own
+// aligned windows of the text, and only the lines that hold a window's first and last byte can be
+// that long, so such a line is copied by as many workgroups as it has windows.
+template <bool FASTQ>
+__global__ __launch_bounds__(PB) void k_parse_copy_long(const ParseState* st, uint64_t max_records, uint64_t seq_capacity,
+                                                        const uint8_t* __restrict__ text, uint64_t n,
+                                                        const uint64_t* __restrict__ line_start,
+                                                        const uint32_t* __restrict__ line_len,
+                                                        const uint8_t* __restrict__ line_head,
+                                                        const uint64_t* __restrict__ line_dst,
+                                                        const uint32_t* __restrict__ line_rank,
+                                                        uint8_t* __restrict__ seq, uint8_t* __restrict__ qual)
+{
+    const uint64_t nrec = st->nrec, nlines = st->nlines;
+    if (st->n_long == 0 || nlines == 0) return;
+    if (st->status != PARSE_OK || nrec > max_records || st->seq_bytes > seq_capacity) return;
+    const uint64_t ntiles = (n + LONG_LINE - 1) / LONG_LINE;
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint64_t t0 = tile * LONG_LINE, t1 = t0 + LONG_LINE < n ? t0 + LONG_LINE : n;
+        uint64_t which[2];
+#pragma unroll
+        for (int c = 0; c < 2; c++) {                    // last line that starts at or before the byte
+            const uint64_t p = c == 0 ? t0 : t1 - 1;
+            uint64_t lo = 0, hi = nlines;                // line_start[lo] <= p (line 0 starts at 0)
+            while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if (line_start[mid] <= p) lo = mid; else hi = mid; }
+            which[c] = lo;
+        }
+#pragma unroll 1
+        for (int c = 0; c < 2; c++) {
+            if (c == 1 && which[1] == which[0]) break;
+            const uint64_t i = which[c];
+            const uint64_t len = line_len[i];
+            if (len <= LONG_LINE) continue;              // block-uniform
+            uint8_t* dst_plane;
+            uint64_t dst;
+            if (FASTQ) {
+                const uint32_t role = (uint32_t)(i & 3);
+                if ((role != 1 && role != 3) || (i >> 2) >= nrec) continue;
+                dst_plane = role == 1 ? seq : qual;
+                dst = line_dst[role == 1 ? i : i - 2];
+            } else {
+                const uint32_t rank = line_rank[i];
+                if (line_head[i] || rank == 0 || rank - 1 >= nrec) continue;
+                dst_plane = seq;
+                dst = line_dst[i];
+            }
+            const uint64_t ls = line_start[i];
+            const uint64_t k0 = (ls > t0 ? ls : t0) - ls, k1 = (ls + len < t1 ? ls + len : t1) - ls;
+            const uint8_t* src = text + ls;
+            uint8_t* out = dst_plane + dst;
+            for (uint64_t p = k0 + 16ull * threadIdx.x; p < k1; p += 16ull * PB) {
+                if (p + 16 <= k1) {
+                    uint4 v;
+                    __builtin_memcpy(&v, src + p, 16);
+                    __builtin_memcpy(out + p, &v, 16);
+                } else {
+                    for (uint64_t k = p; k < k1; k++) out[k] = src[k];
+                }
             }
         }
     }
@@ -591,6 +660,8 @@ static hipError_t launch_parse_t(const uint8_t* text, uint64_t n, int final, uin
                        line_dst, line_rank, offsets, name_pos, name_len);
     hipLaunchKernelGGL((k_parse_copy<FASTQ>), dim3(gc), dim3(PB), 0, s, st, max_records, seq_capacity, text, line_start,
                        line_len, line_head, line_dst, line_rank, seq, qual);
+    hipLaunchKernelGGL((k_parse_copy_long<FASTQ>), dim3(1024), dim3(PB), 0, s, st, max_records, seq_capacity, text, n,
+                       line_start, line_len, line_head, line_dst, line_rank, seq, qual);
     hipLaunchKernelGGL(k_parse_finish, dim3(1), dim3(1), 0, s, st, max_records, seq_capacity, res);
     return hipGetLastError();
 }

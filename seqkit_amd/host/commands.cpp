@@ -232,6 +232,7 @@ class BlockPipe {
         uint64_t cap = 0, head = 0;      // buffer size; where the reader starts to fill
         uint64_t filled = 0;             // bytes the reader put at buffer + head
         bool eof = false;                // the file ended in (or right after) this block
+        bool grown = false;              // enlarged for long records: half of it is headroom
         skh_parse_result res;
     };
     // a queue of block pointers; nullptr from pop() means "closed and empty"
@@ -261,13 +262,18 @@ class BlockPipe {
         std::string error() { std::lock_guard<std::mutex> l(err_mu); return err; }
     };
 
-    static Block* new_block(State& s, uint64_t cap)
+    // Headroom in front of what the reader fills: an eighth of a block of the ordinary size (the
+    // tail is less than one record), half of a block that was enlarged for records longer than that.
+    static uint64_t headroom(const Block& b) { return ((b.grown ? b.cap / 2 : b.cap / 8)) & ~uint64_t(4095); }
+
+    static Block* new_block(State& s, uint64_t cap, bool grown)
     {
         Block* b = new Block;
         PhaseTimer pt(5);
         if (skh_text_alloc(s.ctx, cap, &b->t) != SKH_OK) { s.fail(skh_last_error()); delete b; return nullptr; }
         b->cap = skh_text_capacity(b->t);
-        b->head = (b->cap / 8) & ~uint64_t(4095);
+        b->grown = grown;
+        b->head = headroom(*b);
         return b;
     }
 
@@ -314,8 +320,9 @@ class BlockPipe {
             if (!b || s.stop) break;
             if (tail.size() > b->head) {
                 // the tail does not fit in front of what was read (a record longer than the headroom):
-                // both go into a block large enough for twice as much, which stays in the round
-                Block* nb = new_block(s, 2 * (tail.size() + b->cap));
+                // both go into a block whose headroom holds twice this tail, which stays in the round
+                const uint64_t want = 4 * (uint64_t)tail.size() > 2 * b->cap ? 4 * (uint64_t)tail.size() : 2 * b->cap;
+                Block* nb = new_block(s, want + b->filled, true);
                 if (!nb) break;
                 nb->head = tail.size();
                 memcpy(skh_text_buffer(nb->t) + nb->head, skh_text_buffer(b->t) + b->head, b->filled);
@@ -328,7 +335,7 @@ class BlockPipe {
             uint8_t* buf = skh_text_buffer(b->t);
             uint64_t off = b->head - tail.size(), have = tail.size() + b->filled;
             if (!tail.empty()) memcpy(buf + off, tail.data(), tail.size());
-            b->head = (b->cap / 8) & ~uint64_t(4095);              // for its next round
+            b->head = headroom(*b);                                // for its next round
             tail.clear();
             const bool eof = b->eof;
             if (have == 0) {                                       // the file ended with the block before
@@ -401,7 +408,7 @@ public:
         if (s.fd < 0 && !s.fh) { s.err = "open " + path + ": no such file or directory"; return; }
         if (s.fh) gzbuffer((gzFile)s.fh, 1 << 20);
         for (int k = 0; k < 3; k++) {
-            Block* b = new_block(s, block_bytes);
+            Block* b = new_block(s, block_bytes, false);
             if (!b) return;
             s.all.push_back(b);
             s.free_q.push(b);

@@ -179,6 +179,32 @@ def test_long_records_through_the_driver(cli, oracle_cli, tmp_path):
         assert got[0] == want[0] == 0 and got[1] == want[1]
 
 
+def test_long_lines_and_long_reads(cli, oracle_cli, tmp_path):
+    # records and text lines around and beyond the 32-KiB limit of the lane-group kernels: unwrapped
+    # FASTA (one line per record), long FASTQ reads, every wrap width, fx2tab with sequence columns
+    import numpy as np
+    rng = np.random.default_rng(9)
+    lens = [32767, 32768, 32769, 12, 65536 + 7, 0, 300001, 98304, 1]
+    fa, fq = tmp_path / "unwrapped.fa", tmp_path / "long.fq"
+    with open(fa, "wb") as fh, open(fq, "wb") as fh2:
+        for i, n in enumerate(lens):
+            s = rng.choice(np.frombuffer(b"ACGTNacgtnRY-", np.uint8), size=n).tobytes()
+            q = rng.integers(33, 74, size=n, dtype=np.uint8).tobytes()
+            fh.write(b">u%d some words\n" % i + s + b"\n")
+            if n:
+                fh2.write(b"@q%d x\n" % i + s + b"\n+\n" + q + b"\n")
+    for f in (fa, fq):
+        for argv in (["seq", "-r", "-p"], ["seq", "-w", "0"], ["seq", "-r", "-w", "7"], ["seq", "-p", "-w", "32768"],
+                     ["seq", "-s", "-w", "100"], ["seq", "-r", "-p", "--batch-bytes", "100000"],
+                     ["fx2tab"], ["fx2tab", "-l", "-g"], ["fx2tab", "-n", "-l", "-B", "AT"], ["stats", "-a", "-T"]):
+            want = run_cli(oracle_cli, [a for a in argv if a not in ("--batch-bytes", "100000")] + [str(f)])
+            got = run_cli(cli, argv + [str(f)])
+            assert got[0] == want[0] == 0 and got[1] == want[1], (f.name, argv)
+    want = run_cli(oracle_cli, ["seq", "-q", str(fq)])
+    got = run_cli(cli, ["seq", "-q", str(fq)])
+    assert got[0] == want[0] == 0 and got[1] == want[1]
+
+
 # ---------------------------------------------------------------------------------------- subseq
 
 @pytest.mark.parametrize("f", FILES)
