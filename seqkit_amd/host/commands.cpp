@@ -38,13 +38,14 @@ struct TwoBatches {
 
 // ---- phase timing (SKH_TIMING=1: totals on stderr at exit) ---------------------------------
 struct Phases {
-    double t[6] = {0, 0, 0, 0, 0, 0};
+    double t[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     bool on = getenv("SKH_TIMING") != nullptr;
     static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
     ~Phases()
     {
         if (on) fprintf(stderr, "[timing] read %.3f s, upload+parse %.3f s, kernels %.3f s, format+download %.3f s, "
-                                "write %.3f s, buffer alloc/free %.3f s\n", t[0], t[1], t[2], t[3], t[4], t[5]);
+                                "write %.3f s, buffer alloc/free %.3f s; pipeline: tail copies %.3f s, reader waits %.3f s, "
+                                "parser waits %.3f s, caller waits %.3f s\n", t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], t[8], t[9]);
     }
 };
 Phases g_phases;
@@ -233,6 +234,7 @@ class BlockPipe {
         uint64_t filled = 0;             // bytes the reader put at buffer + head
         bool eof = false;                // the file ended in (or right after) this block
         bool grown = false;              // enlarged for long records: half of it is headroom
+        bool head_line = false;          // FASTA: what the reader put in holds a line that starts with '>'
         skh_parse_result res;
     };
     // a queue of block pointers; nullptr from pop() means "closed and empty"
@@ -258,6 +260,7 @@ class BlockPipe {
         std::mutex err_mu; std::string err;
         std::atomic<bool> stop{false}, reader_done{false};
         bool fastq = false;              // written by the parser before the first block is handed on
+        uint64_t chunk = 0;              // most the reader puts into a block at once (what an ordinary block takes)
         void fail(const std::string& m) { std::lock_guard<std::mutex> l(err_mu); if (err.empty()) err = m; }
         std::string error() { std::lock_guard<std::mutex> l(err_mu); return err; }
     };
@@ -280,11 +283,16 @@ class BlockPipe {
     static void reader(std::shared_ptr<State> sp)
     {
         State& s = *sp;
+        bool kind_known = false, fasta = false;
+        uint8_t prev = 0;                // the byte before the block (0 at the start of the file)
         for (;;) {
-            Block* b = s.free_q.pop();
+            Block* b;
+            { PhaseTimer pt(7); b = s.free_q.pop(); }
             if (!b || s.stop) break;
             uint8_t* buf = skh_text_buffer(b->t) + b->head;
-            const uint64_t room = b->cap - b->head;
+            // an enlarged block is not filled further than an ordinary one: what follows the last
+            // complete record of a block has to be moved to the next one
+            const uint64_t room = b->cap - b->head < s.chunk ? b->cap - b->head : s.chunk;
             b->filled = 0; b->eof = false;
             bool bad = false;
             while (b->filled < room && !b->eof && !s.stop) {
@@ -301,6 +309,25 @@ class BlockPipe {
                 b->filled += (uint64_t)n;
             }
             if (bad || s.stop) break;
+            if (!kind_known && b->filled) {
+                uint64_t k = 0;
+                while (k < b->filled && (buf[k] == '\n' || buf[k] == '\r')) k++;
+                if (k < b->filled) { kind_known = true; fasta = buf[k] == '>'; }
+            }
+            b->head_line = true;                                   // FASTQ: the parser decides
+            if (kind_known && fasta) {
+                // a head line after the first byte of the file: the record before it is complete
+                b->head_line = false;
+                uint64_t p = 0;
+                while (p < b->filled && !b->head_line) {
+                    const uint8_t* q = static_cast<const uint8_t*>(memchr(buf + p, '>', b->filled - p));
+                    if (!q) break;
+                    p = (uint64_t)(q - buf);
+                    b->head_line = (p ? buf[p - 1] : prev) == '\n';
+                    p++;
+                }
+            }
+            if (b->filled) prev = buf[b->filled - 1];
             const bool last = b->eof;
             s.filled_q.push(b);
             if (last) break;
@@ -309,35 +336,88 @@ class BlockPipe {
         s.reader_done = true;
     }
 
+    // memcpy by a few threads (a single one moves 10 GB/s or less, page faults included)
+    static void copy_bytes(uint8_t* dst, const uint8_t* src, uint64_t n)
+    {
+        if (n < (16u << 20)) { memcpy(dst, src, n); return; }
+        const unsigned nthr = 8;
+        const uint64_t part = ((n + nthr - 1) / nthr + 4095) & ~uint64_t(4095);
+        std::vector<std::thread> thr;
+        for (unsigned k = 1; k < nthr && (uint64_t)k * part < n; k++) {
+            const uint64_t a = (uint64_t)k * part, len = a + part < n ? part : n - a;
+            thr.emplace_back([=] { memcpy(dst + a, src + a, len); });
+        }
+        memcpy(dst, src, part < n ? part : n);
+        for (auto& t : thr) t.join();
+    }
+
+    // `b` replaced in the round by a new block of at least `cap` bytes (contents are not copied)
+    static Block* replace_block(State& s, Block* b, uint64_t cap)
+    {
+        Block* nb = new_block(s, cap, true);
+        if (!nb) return nullptr;
+        for (auto& x : s.all) if (x == b) x = nb;
+        return nb;
+    }
+    static void drop_block(Block* b)
+    {
+        { PhaseTimer pt(5); skh_text_free(b->t); }
+        delete b;
+    }
+
     static void parser(std::shared_ptr<State> sp)
     {
         State& s = *sp;
-        std::vector<uint8_t> tail;       // text after the last complete record of the block before
+        std::vector<uint8_t> tail;       // text after the last complete record of the block handed on last
+        // A block without one complete record (a record longer than the block) is kept here and what
+        // the reader delivers next is appended to it, so every byte of a long record is moved once.
+        Block* acc = nullptr;
+        uint64_t acc_off = 0, acc_have = 0;                 // where its text lies
         bool format_known = false;
         uint64_t lines_before = 0;
         for (;;) {
-            Block* b = s.filled_q.pop();
+            Block* b;
+            { PhaseTimer pt(8); b = s.filled_q.pop(); }
             if (!b || s.stop) break;
-            if (tail.size() > b->head) {
-                // the tail does not fit in front of what was read (a record longer than the headroom):
-                // both go into a block whose headroom holds twice this tail, which stays in the round
-                const uint64_t want = 4 * (uint64_t)tail.size() > 2 * b->cap ? 4 * (uint64_t)tail.size() : 2 * b->cap;
-                Block* nb = new_block(s, want + b->filled, true);
-                if (!nb) break;
-                nb->head = tail.size();
-                memcpy(skh_text_buffer(nb->t) + nb->head, skh_text_buffer(b->t) + b->head, b->filled);
-                nb->filled = b->filled; nb->eof = b->eof;
-                for (auto& x : s.all) if (x == b) x = nb;
-                { PhaseTimer pt(5); skh_text_free(b->t); }
-                delete b;
-                b = nb;
+            const double t_tail0 = g_phases.on ? Phases::now() : 0;
+            uint64_t off, have;
+            const bool eof = b->eof, later_head = b->head_line;
+            if (acc) {
+                const uint64_t need = acc_off + acc_have + b->filled;
+                if (need > acc->cap) {
+                    Block* nb = replace_block(s, acc, 2 * (acc_have + b->filled));
+                    if (!nb) break;
+                    copy_bytes(skh_text_buffer(nb->t), skh_text_buffer(acc->t) + acc_off, acc_have);
+                    drop_block(acc);
+                    acc = nb; acc_off = 0;
+                }
+                copy_bytes(skh_text_buffer(acc->t) + acc_off + acc_have, skh_text_buffer(b->t) + b->head, b->filled);
+                acc_have += b->filled;
+                s.free_q.push(b);                                  // back to the reader at once
+                b = acc; off = acc_off; have = acc_have;
+                acc = nullptr;
+            } else {
+                if (tail.size() > b->head && tail.size() + b->filled <= b->cap) {
+                    // the tail does not fit in front of what was read, but the block holds both
+                    memmove(skh_text_buffer(b->t) + tail.size(), skh_text_buffer(b->t) + b->head, b->filled);
+                    b->head = tail.size();
+                } else if (tail.size() > b->head) {
+                    // both go into a block of twice the size (half of it headroom), which stays in the round
+                    Block* nb = replace_block(s, b, 2 * (tail.size() + b->filled));
+                    if (!nb) break;
+                    nb->head = tail.size();
+                    copy_bytes(skh_text_buffer(nb->t) + nb->head, skh_text_buffer(b->t) + b->head, b->filled);
+                    nb->filled = b->filled; nb->eof = b->eof;
+                    drop_block(b);
+                    b = nb;
+                }
+                off = b->head - tail.size(); have = tail.size() + b->filled;
+                if (!tail.empty()) copy_bytes(skh_text_buffer(b->t) + off, tail.data(), tail.size());
+                tail.clear();
             }
+            b->head = headroom(*b);                                // for its next round with the reader
             uint8_t* buf = skh_text_buffer(b->t);
-            uint64_t off = b->head - tail.size(), have = tail.size() + b->filled;
-            if (!tail.empty()) memcpy(buf + off, tail.data(), tail.size());
-            b->head = headroom(*b);                                // for its next round
-            tail.clear();
-            const bool eof = b->eof;
+            if (g_phases.on) g_phases.t[6] += Phases::now() - t_tail0;
             if (have == 0) {                                       // the file ended with the block before
                 if (eof) break;
                 s.free_q.push(b);
@@ -357,6 +437,12 @@ class BlockPipe {
                 else { s.fail("error when parsing " + s.path + ": invalid FASTA/Q format"); break; }
                 format_known = true;
             }
+            // FASTA before the end of the file: a record is complete when a later head line is in sight;
+            // without one the upload and the parse would be for nothing
+            if (!s.fastq && !eof && !later_head) {
+                acc = b; acc_off = off; acc_have = have;
+                continue;
+            }
             skh_parse_result res;
             {
                 PhaseTimer pt(1);
@@ -371,14 +457,20 @@ class BlockPipe {
                        (s.fastq ? " (multi-line FASTQ needs --host-parse)" : ""));
                 break;
             }
-            if (res.nrec == 0) res.consumed = 0;                   // nothing complete: all of it is tail
-            if (!eof) tail.assign(buf + off + res.consumed, buf + off + have);
-            lines_before += s.fastq ? res.nrec * 4 : res.lines;
             if (res.nrec == 0) {
                 if (eof) break;
-                s.free_q.push(b);
+                acc = b; acc_off = off; acc_have = have;           // nothing complete yet: more text is needed
                 continue;
             }
+            if (!eof) {
+                PhaseTimer pt(6);
+                const uint64_t keep = have - res.consumed;
+                // (capacity doubles: a fresh allocation of this size is paid for in page faults)
+                if (keep > tail.capacity()) { tail.clear(); tail.shrink_to_fit(); tail.reserve(2 * keep); }
+                tail.resize(keep);
+                copy_bytes(tail.data(), buf + off + res.consumed, keep);
+            }
+            lines_before += s.fastq ? res.nrec * 4 : res.lines;
             b->res = res;
             s.parsed_q.push(b);
             if (eof) break;
@@ -410,6 +502,7 @@ public:
         for (int k = 0; k < 3; k++) {
             Block* b = new_block(s, block_bytes, false);
             if (!b) return;
+            if (k == 0) s.chunk = b->cap - b->head;
             s.all.push_back(b);
             s.free_q.push(b);
         }
@@ -448,7 +541,7 @@ public:
     bool next(skh_parse_result& res)
     {
         if (cur_) { s_->free_q.push(cur_); cur_ = nullptr; }
-        cur_ = s_->parsed_q.pop();
+        { PhaseTimer pt(9); cur_ = s_->parsed_q.pop(); }
         if (!cur_) return false;
         res = cur_->res;
         return true;
