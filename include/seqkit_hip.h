@@ -323,6 +323,13 @@ int skh_text_parse(skh_ctx *ctx, skh_text *t, uint64_t text_bytes, int format, i
  * skh_text_buffer(). */
 int skh_text_parse_at(skh_ctx *ctx, skh_text *t, uint64_t text_offset, uint64_t text_bytes, int format,
                       int final, skh_parse_result *out);
+/* Starts the upload of buffer bytes [offset, offset + nbytes) and returns at once: a reader that
+ * runs ahead calls it as soon as it has filled a block, so the bulk of the block crosses the link
+ * while the block before it is still being parsed.  The next skh_text_parse_at on the block whose
+ * text covers that range uploads only the bytes around it (another text range uploads everything,
+ * as without this call).  The range must not be written to between this call and the return of
+ * that parse. */
+int skh_text_upload(skh_ctx *ctx, skh_text *t, uint64_t offset, uint64_t nbytes);
 /* Copies offsets[first .. first+count) of the parsed block to host memory. */
 int skh_text_offsets(skh_ctx *ctx, skh_text *t, uint64_t first, uint64_t count, uint64_t *offsets);
 /* Copies sequence bytes [first_byte, first_byte+count) of the block to host memory
@@ -334,6 +341,13 @@ int skh_text_revcomp(skh_ctx *ctx, skh_text *t, const uint8_t *lut, int do_rever
  * block, valid until its next call. */
 int skh_text_format_seq(skh_ctx *ctx, skh_text *t, const skh_seq_format *fmt,
                         const uint8_t **out, uint64_t *out_bytes);
+/* Split forms for overlap: *_submit run the formatter, start the download of the output and
+ * return; skh_text_output_wait blocks until the output has arrived (*out as above; 0 bytes when
+ * nothing was submitted).  Between the two the caller works on another block, whose kernels then
+ * run beside this block's download. */
+int skh_text_format_seq_submit(skh_ctx *ctx, skh_text *t, const skh_seq_format *fmt);
+int skh_text_format_tab_submit(skh_ctx *ctx, skh_text *t, const skh_tab_format *fmt);
+int skh_text_output_wait(skh_ctx *ctx, skh_text *t, const uint8_t **out, uint64_t *out_bytes);
 /* skh_count_dev on the block; the counts stay on the device in slot `pass`
  * (< SKH_TAB_MAX_PASSES) for skh_text_format_tab. */
 int skh_text_count(skh_ctx *ctx, skh_text *t, const uint8_t class_of[256], uint32_t nclass, uint32_t pass);

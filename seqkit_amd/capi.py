@@ -108,10 +108,14 @@ SYMBOLS = {
     "skh_text_capacity": (C.c_uint64, [vp]),
     "skh_text_parse": (C.c_int, [vp, vp, C.c_uint64, C.c_int, C.c_int, C.POINTER(ParseResult)]),
     "skh_text_parse_at": (C.c_int, [vp, vp, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.POINTER(ParseResult)]),
+    "skh_text_upload": (C.c_int, [vp, vp, C.c_uint64, C.c_uint64]),
     "skh_text_offsets": (C.c_int, [vp, vp, C.c_uint64, C.c_uint64, u64p]),
     "skh_text_sequence": (C.c_int, [vp, vp, C.c_uint64, C.c_uint64, u8p]),
     "skh_text_revcomp": (C.c_int, [vp, vp, u8p, C.c_int, C.c_int]),
     "skh_text_format_seq": (C.c_int, [vp, vp, C.POINTER(SeqFormat), C.POINTER(vp), u64p]),
+    "skh_text_format_seq_submit": (C.c_int, [vp, vp, C.POINTER(SeqFormat)]),
+    "skh_text_format_tab_submit": (C.c_int, [vp, vp, C.POINTER(TabFormat)]),
+    "skh_text_output_wait": (C.c_int, [vp, vp, C.POINTER(vp), u64p]),
     "skh_text_stats": (C.c_int, [vp, vp, u8p, C.POINTER(StatsPartial)]),
     "skh_batch_alloc": (C.c_int, [vp, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(vp)]),
     "skh_batch_free": (None, [vp]),

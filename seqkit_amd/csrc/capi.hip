@@ -779,6 +779,9 @@ struct skh_text {
     int fastq = 0;
     uint64_t nrec = 0, seq_bytes = 0, text_bytes = 0;
     uint64_t text_off = 0;                  // where the parsed text starts in h_text (skh_text_parse_at)
+    uint64_t out_pending = 0;               // bytes of h_out on their way (skh_text_format_*_submit)
+    uint8_t* d_stage = nullptr;             // skh_text_upload: device copy of h_text at the same offsets
+    uint64_t up_off = 0, up_bytes = 0;      // the range uploaded ahead of the next parse (up_bytes = 0: none)
     bool transformed = false;               // planes of the block now live in d_seq2 / d_qual2
     // what the later calls read: the parsed tables, or those of the slices after skh_text_subseq
     const uint64_t *v_offs = nullptr, *v_npos = nullptr;
@@ -869,6 +872,7 @@ void skh_text_free(skh_text* t)
     (void)hipSetDevice(t->ctx->device);
     if (t->stream) { (void)hipStreamSynchronize(t->stream); (void)hipStreamDestroy(t->stream); }
     text_free_lines(t);
+    (void)hipFree(t->d_stage);
     (void)hipFree(t->d_text); (void)hipFree(t->d_seq); (void)hipFree(t->d_qual); (void)hipFree(t->d_seq2); (void)hipFree(t->d_qual2);
     (void)hipFree(t->d_out); (void)hipFree(t->d_res);
     (void)hipFree(t->d_slices); (void)hipFree(t->d_offs2); (void)hipFree(t->d_npos2); (void)hipFree(t->d_nlen2);
@@ -894,9 +898,23 @@ int skh_text_parse_at(skh_ctx* ctx, skh_text* t, uint64_t text_offset, uint64_t 
     HIP_TRY(hipSetDevice(ctx->device));
     // the text goes to the start of the device buffer wherever it starts on the host; the bytes of the
     // last, partial 16-byte chunk beyond text_bytes are never looked at by the parser
-    uint64_t up = skh_padded_size(text_bytes);
-    if (up > t->cap - text_offset) up = text_bytes;
-    if (up) HIP_TRY(hipMemcpyAsync(t->d_text, t->h_text + text_offset, up, hipMemcpyHostToDevice, t->stream));
+    const uint64_t text_end = text_offset + text_bytes;
+    if (t->up_bytes && t->up_off >= text_offset && t->up_off + t->up_bytes <= text_end) {
+        // most of the text is on its way already (skh_text_upload): the bytes around it follow, and a
+        // device copy moves the whole to the aligned start of the text buffer
+        if (t->up_off > text_offset)
+            HIP_TRY(hipMemcpyAsync(t->d_stage + text_offset, t->h_text + text_offset, t->up_off - text_offset,
+                                   hipMemcpyHostToDevice, t->stream));
+        const uint64_t up_end = t->up_off + t->up_bytes;
+        if (text_end > up_end)
+            HIP_TRY(hipMemcpyAsync(t->d_stage + up_end, t->h_text + up_end, text_end - up_end, hipMemcpyHostToDevice, t->stream));
+        HIP_TRY(hipMemcpyAsync(t->d_text, t->d_stage + text_offset, text_bytes, hipMemcpyDeviceToDevice, t->stream));
+    } else {
+        uint64_t up = skh_padded_size(text_bytes);
+        if (up > t->cap - text_offset) up = text_bytes;
+        if (up) HIP_TRY(hipMemcpyAsync(t->d_text, t->h_text + text_offset, up, hipMemcpyHostToDevice, t->stream));
+    }
+    t->up_bytes = 0;
     t->text_off = text_offset;
     for (;;) {
         int rc = skh_parse_dev(ctx, t->d_text, text_bytes, format, final, t->d_seq, t->d_qual, t->cap, t->d_offs,
@@ -918,6 +936,20 @@ int skh_text_parse_at(skh_ctx* ctx, skh_text* t, uint64_t text_offset, uint64_t 
     t->text_bytes = text_bytes;
     t->transformed = false;
     t->v_offs = t->d_offs; t->v_npos = t->d_npos; t->v_nlen = t->d_nlen; t->v_text = t->d_text;
+    return SKH_OK;
+}
+
+int skh_text_upload(skh_ctx* ctx, skh_text* t, uint64_t offset, uint64_t nbytes)
+{
+    if (!ctx || !t) return fail(SKH_EINVAL, "NULL argument");
+    if (offset > t->cap || nbytes > t->cap - offset) return fail(SKH_ECAPACITY, "range beyond the block's buffer");
+    HIP_TRY(hipSetDevice(ctx->device));
+    t->up_bytes = 0;
+    if (nbytes == 0) return SKH_OK;
+    if (!t->d_stage) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&t->d_stage), t->cap));
+    HIP_TRY(hipMemcpyAsync(t->d_stage + offset, t->h_text + offset, nbytes, hipMemcpyHostToDevice, t->stream));
+    t->up_off = offset;
+    t->up_bytes = nbytes;
     return SKH_OK;
 }
 
@@ -959,10 +991,37 @@ int skh_text_revcomp(skh_ctx* ctx, skh_text* t, const uint8_t* lut, int do_rever
     return SKH_OK;
 }
 
+int skh_text_output_wait(skh_ctx* ctx, skh_text* t, const uint8_t** out, uint64_t* out_bytes)
+{
+    if (!ctx || !t || !out || !out_bytes) return fail(SKH_EINVAL, "NULL argument");
+    *out = nullptr; *out_bytes = 0;
+    if (t->out_pending == 0) return SKH_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    *out = t->h_out;
+    *out_bytes = t->out_pending;
+    t->out_pending = 0;
+    return SKH_OK;
+}
+
 int skh_text_format_seq(skh_ctx* ctx, skh_text* t, const skh_seq_format* fmt, const uint8_t** out, uint64_t* out_bytes)
 {
-    if (!ctx || !t || !fmt || !out || !out_bytes) return fail(SKH_EINVAL, "NULL argument");
-    *out = nullptr; *out_bytes = 0;
+    if (!out || !out_bytes) return fail(SKH_EINVAL, "NULL argument");
+    const int rc = skh_text_format_seq_submit(ctx, t, fmt);
+    return rc ? rc : skh_text_output_wait(ctx, t, out, out_bytes);
+}
+
+int skh_text_format_tab(skh_ctx* ctx, skh_text* t, const skh_tab_format* fmt, const uint8_t** out, uint64_t* out_bytes)
+{
+    if (!out || !out_bytes) return fail(SKH_EINVAL, "NULL argument");
+    const int rc = skh_text_format_tab_submit(ctx, t, fmt);
+    return rc ? rc : skh_text_output_wait(ctx, t, out, out_bytes);
+}
+
+int skh_text_format_seq_submit(skh_ctx* ctx, skh_text* t, const skh_seq_format* fmt)
+{
+    if (!ctx || !t || !fmt) return fail(SKH_EINVAL, "NULL argument");
+    t->out_pending = 0;
     if (t->nrec == 0) return SKH_OK;
     HIP_TRY(hipSetDevice(ctx->device));
     const uint8_t* seq = t->transformed ? t->d_seq2 : t->d_seq;
@@ -978,9 +1037,7 @@ int skh_text_format_seq(skh_ctx* ctx, skh_text* t, const skh_seq_format* fmt, co
         const skh_format_result r = *static_cast<skh_format_result*>(t->h_res);
         if (r.status == SKH_PARSE_OK) {
             HIP_TRY(hipMemcpyAsync(t->h_out, t->d_out, r.out_bytes, hipMemcpyDeviceToHost, t->stream));
-            HIP_TRY(hipStreamSynchronize(t->stream));
-            *out = t->h_out;
-            *out_bytes = r.out_bytes;
+            t->out_pending = r.out_bytes;
             return SKH_OK;
         }
         hipError_t e = text_alloc_out(t, r.out_bytes + r.out_bytes / 16 + 4096);
@@ -1007,10 +1064,10 @@ int skh_text_count(skh_ctx* ctx, skh_text* t, const uint8_t class_of[256], uint3
                          t->d_counts[pass], t->stream);
 }
 
-int skh_text_format_tab(skh_ctx* ctx, skh_text* t, const skh_tab_format* fmt, const uint8_t** out, uint64_t* out_bytes)
+int skh_text_format_tab_submit(skh_ctx* ctx, skh_text* t, const skh_tab_format* fmt)
 {
-    if (!ctx || !t || !fmt || !out || !out_bytes) return fail(SKH_EINVAL, "NULL argument");
-    *out = nullptr; *out_bytes = 0;
+    if (!ctx || !t || !fmt) return fail(SKH_EINVAL, "NULL argument");
+    t->out_pending = 0;
     if (t->nrec == 0) return SKH_OK;
     HIP_TRY(hipSetDevice(ctx->device));
     const uint8_t* seq = t->transformed ? t->d_seq2 : t->d_seq;
@@ -1026,9 +1083,7 @@ int skh_text_format_tab(skh_ctx* ctx, skh_text* t, const skh_tab_format* fmt, co
         const skh_format_result r = *static_cast<skh_format_result*>(t->h_res);
         if (r.status == SKH_PARSE_OK) {
             HIP_TRY(hipMemcpyAsync(t->h_out, t->d_out, r.out_bytes, hipMemcpyDeviceToHost, t->stream));
-            HIP_TRY(hipStreamSynchronize(t->stream));
-            *out = t->h_out;
-            *out_bytes = r.out_bytes;
+            t->out_pending = r.out_bytes;
             return SKH_OK;
         }
         hipError_t e = text_alloc_out(t, r.out_bytes + r.out_bytes / 16 + 4096);

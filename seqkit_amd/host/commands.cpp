@@ -261,6 +261,7 @@ class BlockPipe {
         std::atomic<bool> stop{false}, reader_done{false};
         bool fastq = false;              // written by the parser before the first block is handed on
         uint64_t chunk = 0;              // most the reader puts into a block at once (what an ordinary block takes)
+        uint64_t block_bytes = 0;        // size of an ordinary block
         void fail(const std::string& m) { std::lock_guard<std::mutex> l(err_mu); if (err.empty()) err = m; }
         std::string error() { std::lock_guard<std::mutex> l(err_mu); return err; }
     };
@@ -328,6 +329,12 @@ class BlockPipe {
                 }
             }
             if (b->filled) prev = buf[b->filled - 1];
+            // the block starts to cross the link now, while the block before it is parsed (not when
+            // it can only be appended to a record that is still growing)
+            if (skh_text_upload(s.ctx, b->t, b->head, b->head_line ? b->filled : 0) != SKH_OK) {
+                s.fail(skh_last_error());
+                break;
+            }
             const bool last = b->eof;
             s.filled_q.push(b);
             if (last) break;
@@ -375,6 +382,12 @@ class BlockPipe {
         uint64_t acc_off = 0, acc_have = 0;                 // where its text lies
         bool format_known = false;
         uint64_t lines_before = 0;
+        for (int k = 1; k < 4 && !s.stop; k++) {
+            Block* b = new_block(s, s.block_bytes, false);
+            if (!b) { s.stop = true; break; }
+            s.all.push_back(b);
+            s.free_q.push(b);
+        }
         for (;;) {
             Block* b;
             { PhaseTimer pt(8); b = s.filled_q.pop(); }
@@ -401,6 +414,7 @@ class BlockPipe {
                     // the tail does not fit in front of what was read, but the block holds both
                     memmove(skh_text_buffer(b->t) + tail.size(), skh_text_buffer(b->t) + b->head, b->filled);
                     b->head = tail.size();
+                    skh_text_upload(s.ctx, b->t, 0, 0);            // what the reader sent ahead lies elsewhere now
                 } else if (tail.size() > b->head) {
                     // both go into a block of twice the size (half of it headroom), which stays in the round
                     Block* nb = replace_block(s, b, 2 * (tail.size() + b->filled));
@@ -499,13 +513,13 @@ public:
         }
         if (s.fd < 0 && !s.fh) { s.err = "open " + path + ": no such file or directory"; return; }
         if (s.fh) gzbuffer((gzFile)s.fh, 1 << 20);
-        for (int k = 0; k < 3; k++) {
-            Block* b = new_block(s, block_bytes, false);
-            if (!b) return;
-            if (k == 0) s.chunk = b->cap - b->head;
-            s.all.push_back(b);
-            s.free_q.push(b);
-        }
+        // the first block here, the other three by the parser thread while the reader fills this one
+        Block* b = new_block(s, block_bytes, false);
+        if (!b) return;
+        s.chunk = b->cap - b->head;
+        s.block_bytes = block_bytes;
+        s.all.push_back(b);
+        s.free_q.push(b);
         reader_ = std::thread(reader, s_);
         parser_ = std::thread(parser, s_);
     }
@@ -551,6 +565,11 @@ public:
     {
         if (cur_) { s_->free_q.push(cur_); cur_ = nullptr; }
     }
+    // The caller keeps the current block beyond the next call of next() (its output is still on its
+    // way to the host); release() hands it back.
+    void* hold() { Block* b = cur_; cur_ = nullptr; return b; }
+    static skh_text* text_of(void* held) { return static_cast<Block*>(held)->t; }
+    void release(void* held) { if (held) s_->free_q.push(static_cast<Block*>(held)); }
 
 private:
     std::shared_ptr<State> s_;
@@ -585,9 +604,25 @@ int seq_text_path(const GlobalOpts& g, const SeqOpts& o, const std::vector<std::
         int ab = -1;                                  // the file's alphabet: -t, or guessed from its first record
         std::string pending_error;                    // an invalid record: reported after the records before it
         skh_parse_result res;
-        while (pending_error.empty() && tb.next(res)) {
+        // the output of a block is downloaded while the next block is worked on: `held` is the block
+        // whose text is still on its way
+        void* held = nullptr;
+        auto flush_held = [&]() -> int {
+            if (!held) return 0;
+            const uint8_t* text = nullptr;
+            uint64_t nbytes = 0;
+            {
+                PhaseTimer pt(3);
+                if (skh_text_output_wait(ctx, BlockPipe::text_of(held), &text, &nbytes) != SKH_OK) return fatal(skh_last_error());
+            }
+            { PhaseTimer pt(4); out.write(text, nbytes); }
+            tb.release(held);
+            held = nullptr;
+            return 0;
+        };
+        auto one_block = [&]() -> int {
             skh_text* t = tb.block();
-            if (res.nrec == 0) { tb.advance(res); continue; }
+            if (res.nrec == 0) { tb.advance(res); return 0; }
             if (ab < 0 && (o.complement || o.validate)) {
                 std::string err;
                 ab = first_record_alphabet(ctx, t, g, g.alphabet, err);
@@ -609,7 +644,7 @@ int seq_text_path(const GlobalOpts& g, const SeqOpts& o, const std::vector<std::
                                     alphabet_name(ab) + " letter: " + std::string(1, (char)vr.letter) + ")";
                     if (skh_text_truncate(ctx, t, vr.record) != SKH_OK) return fatal(skh_last_error());
                     res.nrec = vr.record;
-                    if (res.nrec == 0) break;
+                    if (res.nrec == 0) return 0;
                 }
             }
             if (o.complement && !lut_ready) {
@@ -651,17 +686,21 @@ int seq_text_path(const GlobalOpts& g, const SeqOpts& o, const std::vector<std::
                 if (f.print_qual && !tb.is_fastq()) f.print_qual = 0;      // a FASTA file after a FASTQ one
                 f.only_id = o.only_id;
                 f.mark = is_fastq ? '@' : '>';
-                const uint8_t* text = nullptr;
-                uint64_t nbytes = 0;
                 {
                     PhaseTimer pt(3);
-                    if (skh_text_format_seq(ctx, t, &f, &text, &nbytes) != SKH_OK) return fatal(skh_last_error());
+                    if (skh_text_format_seq_submit(ctx, t, &f) != SKH_OK) return fatal(skh_last_error());
                 }
-                PhaseTimer pt(4);
-                out.write(text, nbytes);
+                if (int rc = flush_held()) return rc;
+                held = tb.hold();
+                return 0;
             }
             if (pending_error.empty()) tb.advance(res);
+            return 0;
+        };
+        while (pending_error.empty() && tb.next(res)) {
+            if (int rc = one_block()) { flush_held(); return rc; }
         }
+        if (int rc = flush_held()) return rc;
         if (!pending_error.empty()) { out.flush(); return fatal(pending_error); }
         if (!tb.error().empty()) return fatal(tb.error());
     }
@@ -852,28 +891,45 @@ int cmd_fx2tab(const GlobalOpts& g, const Fx2tabOpts& o, const std::vector<std::
             BlockPipe tb(ctx.c, file, g.text_block_bytes);
             if (!tb.ok()) return fatal(tb.error());
             skh_parse_result res;
-            while (tb.next(res)) {
-                skh_text* t = tb.block();
-                if (res.nrec) {
-                    {
-                        PhaseTimer pt(2);
-                        for (size_t ps = 0; ps < npass; ps++)
-                            if (skh_text_count(ctx.c, t, pass_table[ps].data(), pass_nclass[ps], (uint32_t)ps) != SKH_OK)
-                                return fatal(skh_last_error());
-                    }
-                    tf.print_seq = !o.only_name;
-                    tf.print_qual = !o.only_name && tb.is_fastq();
-                    const uint8_t* text = nullptr;
-                    uint64_t nbytes = 0;
-                    {
-                        PhaseTimer pt(3);
-                        if (skh_text_format_tab(ctx.c, t, &tf, &text, &nbytes) != SKH_OK) return fatal(skh_last_error());
-                    }
-                    PhaseTimer pt(4);
-                    out.write(text, nbytes);
+            // the rows of a block are downloaded while the next block is counted: `held` is the block
+            // whose text is still on its way
+            void* held = nullptr;
+            auto flush_held = [&]() -> int {
+                if (!held) return 0;
+                const uint8_t* text = nullptr;
+                uint64_t nbytes = 0;
+                {
+                    PhaseTimer pt(3);
+                    if (skh_text_output_wait(ctx.c, BlockPipe::text_of(held), &text, &nbytes) != SKH_OK) return fatal(skh_last_error());
                 }
-                tb.advance(res);
+                { PhaseTimer pt(4); out.write(text, nbytes); }
+                tb.release(held);
+                held = nullptr;
+                return 0;
+            };
+            auto one_block = [&]() -> int {
+                skh_text* t = tb.block();
+                if (res.nrec == 0) { tb.advance(res); return 0; }
+                {
+                    PhaseTimer pt(2);
+                    for (size_t ps = 0; ps < npass; ps++)
+                        if (skh_text_count(ctx.c, t, pass_table[ps].data(), pass_nclass[ps], (uint32_t)ps) != SKH_OK)
+                            return fatal(skh_last_error());
+                }
+                tf.print_seq = !o.only_name;
+                tf.print_qual = !o.only_name && tb.is_fastq();
+                {
+                    PhaseTimer pt(3);
+                    if (skh_text_format_tab_submit(ctx.c, t, &tf) != SKH_OK) return fatal(skh_last_error());
+                }
+                if (int rc = flush_held()) return rc;
+                held = tb.hold();
+                return 0;
+            };
+            while (tb.next(res)) {
+                if (int rc = one_block()) { flush_held(); return rc; }
             }
+            if (int rc = flush_held()) return rc;
             if (!tb.error().empty()) return fatal(tb.error());
         }
         return 0;

@@ -46,10 +46,12 @@ class Block:
     def close(self):
         self.lib.skh_text_free(self.t)
 
-    def parse_at(self, text, off, fmt, final=1):
+    def parse_at(self, text, off, fmt, final=1, ahead=None):
         from seqkit_amd.capi import ParseResult
         self.buf[:] = 0x40                          # '@': stale bytes around the text must not matter
         self.buf[off:off + len(text)] = np.frombuffer(text, np.uint8)
+        if ahead is not None:                       # (offset, nbytes) sent ahead of the parse, as a reader does
+            self.lib.check(self.lib.skh_text_upload(self.ctx, self.t, ahead[0], ahead[1]))
         res = ParseResult()
         self.lib.check(self.lib.skh_text_parse_at(self.ctx, self.t, off, len(text), fmt, final, C.byref(res)))
         return res
@@ -127,7 +129,11 @@ def test_blockwise_tail_carry(lib, ctx, plain_fixtures):
             final = int(pos >= len(text))
             assert len(tail) <= head
             chunk = tail + body
-            res = blk.parse_at(chunk, head - len(tail), 2, final)
+            # every other piece: the body goes ahead (skh_text_upload), the tail follows with the parse;
+            # now and then a range that the text does not cover, which the parse has to ignore
+            step = len(lens) % 3
+            ahead = None if step == 0 else (head, len(body)) if step == 1 else (0, 64)
+            res = blk.parse_at(chunk, head - len(tail), 2, final, ahead)
             assert res.status == 0
             o = np.zeros(res.nrec + 1, np.uint64)
             lib.check(lib.skh_text_offsets(ctx, blk.t, 0, res.nrec + 1, o.ctypes.data_as(C.POINTER(C.c_uint64))))
