@@ -205,6 +205,41 @@ def test_long_lines_and_long_reads(cli, oracle_cli, tmp_path):
     assert got[0] == want[0] == 0 and got[1] == want[1]
 
 
+def test_large_output_to_regular_files(cli, oracle_cli, tmp_path):
+    # tens of megabytes of output into regular files: -o, stdout redirected to a file that already
+    # holds text, and a file opened for appending
+    import subprocess
+    import numpy as np
+    rng = np.random.default_rng(21)
+    n, L = 120_000, 150
+    seq = np.frombuffer(b"ACGTN", np.uint8)[rng.integers(0, 5, (n, L))]
+    qual = rng.integers(35, 74, (n, L), dtype=np.uint8)
+    fq = tmp_path / "big.fq"
+    with open(fq, "wb") as fh:
+        for i in range(n):
+            fh.write(b"@r%d extra\n" % i + seq[i].tobytes() + b"\n+\n" + qual[i].tobytes() + b"\n")
+    want = run_cli(oracle_cli, ["seq", "-r", "-p", str(fq)])
+    assert want[0] == 0 and len(want[1]) > (32 << 20)
+    out1 = tmp_path / "o1.fq"
+    assert run_cli(cli, ["seq", "-r", "-p", "-o", str(out1), str(fq)])[0] == 0
+    assert out1.read_bytes() == want[1]
+    out2 = tmp_path / "o2.fq"
+    with open(out2, "wb") as fh:
+        fh.write(b"before\n")
+        fh.flush()
+        assert subprocess.run([cli, "seq", "-r", "-p", str(fq)], stdout=fh, timeout=300).returncode == 0
+    assert out2.read_bytes() == b"before\n" + want[1]
+    out3 = tmp_path / "o3.fq"
+    out3.write_bytes(b"before\n")
+    with open(out3, "ab") as fh:
+        assert subprocess.run([cli, "seq", "-r", "-p", str(fq)], stdout=fh, timeout=300).returncode == 0
+    assert out3.read_bytes() == b"before\n" + want[1]
+    tab = run_cli(oracle_cli, ["fx2tab", str(fq)])
+    out4 = tmp_path / "o4.tsv"
+    assert run_cli(cli, ["fx2tab", "-o", str(out4), str(fq)])[0] == 0
+    assert out4.read_bytes() == tab[1]
+
+
 # ---------------------------------------------------------------------------------------- subseq
 
 @pytest.mark.parametrize("f", FILES)
