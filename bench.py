@@ -13,8 +13,9 @@ collective in the data path); the `stats` totals are all-reduced once over RCCL 
 the timed loop and checked.
 
 One JSON line on rank 0: value = bases processed by all ranks per second of the
-slowest rank, plus per-kernel roofline figures from HIP events on the launch stream
-and the CPU oracle timed on a bounded sample.
+slowest rank, plus per-kernel roofline figures from HIP events on the launch stream,
+the CPU oracle timed on a bounded sample and, at N = 1, the end-to-end rate of the
+`seqkit-hip` driver on the same batch written as a FASTQ file (`end_to_end`, never `value`).
 """
 import argparse
 import ctypes as C
@@ -49,6 +50,7 @@ def parse():
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the file-to-file run of the driver")
     return ap.parse_args()
 
 
@@ -103,6 +105,73 @@ def cpu_baseline(seconds, L, lut, cls):
     return {"value": round(bases / el / 1e9, 4), "unit": "Gbases/s", "cores": 1, "kind": "port",
             "sample": "%d passes over %d x %d bp FASTQ records (%.1f s): oracle reverse-complement + quality "
                       "reversal + 4-class count, plain C, 1 thread" % (done, nrec, L, el)}
+
+
+def write_fastq_text(path, nrec, L, seq, qual):
+    """The resident batch as FASTQ text (four lines per record, names of fixed width), assembled on
+    the GPU a million records at a time and written to `path`."""
+    import torch
+    dev = seq.device
+    head, tail = b"@SIM:1:FC:1:", b" 1:N:0:ATCACG\n"
+    nd = 9
+    w1 = len(head) + nd + len(tail)
+    width = w1 + 2 * L + 4
+    pow10 = torch.tensor([10 ** (nd - 1 - k) for k in range(nd)], dtype=torch.int64, device=dev)
+    with open(path, "wb") as fh:
+        for a in range(0, nrec, 1_000_000):
+            b = min(nrec, a + 1_000_000)
+            t = torch.empty((b - a, width), dtype=torch.uint8, device=dev)
+            t[:, :len(head)] = torch.tensor(list(head), dtype=torch.uint8, device=dev)
+            ids = torch.arange(a, b, dtype=torch.int64, device=dev)
+            t[:, len(head):len(head) + nd] = ((ids[:, None] // pow10) % 10 + ord("0")).to(torch.uint8)
+            t[:, len(head) + nd:w1] = torch.tensor(list(tail), dtype=torch.uint8, device=dev)
+            t[:, w1:w1 + L] = seq[a * L:b * L].view(b - a, L)
+            t[:, w1 + L:w1 + L + 3] = torch.tensor(list(b"\n+\n"), dtype=torch.uint8, device=dev)
+            t[:, w1 + L + 3:w1 + 2 * L + 3] = qual[a * L:b * L].view(b - a, L)
+            t[:, width - 1] = ord("\n")
+            t.cpu().numpy().tofile(fh)
+            del t
+    return os.path.getsize(path)
+
+
+def end_to_end(nrec, L, seq, qual):
+    """File text in, file text out: `seqkit-hip seq -r -p` (the C++ driver over the C ABI: read, upload,
+    GPU parse, kernels, GPU formatting, download, write) on the batch written as a FASTQ file, page
+    cache warm, output to /dev/null, process start to exit; the CPU restatement's command-line form
+    on the first tenth of the same file beside it.  None when a binary is missing."""
+    import shutil
+    import tempfile
+    drv = os.path.join(ROOT, "seqkit_amd", "seqkit-hip")
+    ora = os.path.join(ROOT, "oracle", "seqkit_oracle")
+    if not os.path.exists(drv):
+        return None
+    d = tempfile.mkdtemp(prefix="skh_e2e_")
+    try:
+        fq, small = os.path.join(d, "batch.fq"), os.path.join(d, "tenth.fq")
+        nbytes = write_fastq_text(fq, nrec, L, seq, qual)
+        n_small = max(nrec // 10, 1)
+        with open(fq, "rb") as a, open(small, "wb") as b:
+            b.write(a.read(nbytes // nrec * n_small))
+        with open(os.devnull, "wb") as null:
+            def wall(argv):
+                t0 = time.perf_counter()
+                rc = subprocess.call(argv, stdout=null)
+                return time.perf_counter() - t0 if rc == 0 else None
+            wall([drv, "stats", small])                         # first use of the GPU by another process
+            runs = [wall([drv, "seq", "-r", "-p", fq]) for _ in range(3)]
+            cpu = wall([ora, "seq", "-r", "-p", small]) if os.path.exists(ora) else None
+        if any(r is None for r in runs):
+            return None
+        best = min(runs)
+        out = {"command": "seqkit-hip seq -r -p batch.fq > /dev/null", "value": round(nrec * L / best / 1e9, 3),
+               "unit": "Gbases/s", "wall_s": round(best, 4), "input_bytes": nbytes,
+               "note": "best of 3, page cache warm, process start to exit, host<->device copies included"}
+        if cpu:
+            out["cpu"] = {"command": "oracle seq -r -p (plain C restatement, 1 thread) on the first %d records" % n_small,
+                          "value": round(n_small * L / cpu / 1e9, 3), "unit": "Gbases/s", "wall_s": round(cpu, 4)}
+        return out
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def main():
@@ -261,6 +330,9 @@ def main():
         }
         if args.cpu_seconds > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, L, lut, cls)
+        if not args.no_e2e and world == 1:
+            torch.cuda.synchronize()
+            out["end_to_end"] = end_to_end(nrec, L, seq, qual)
         print(json.dumps(out), flush=True)
     lib.skh_destroy(ctx)
     if world > 1:
