@@ -1377,7 +1377,7 @@ int cmd_subseq(const GlobalOpts& g, const SubseqOpts& o, const std::vector<std::
     std::vector<skh_slice> slices;
     std::string names;
     for (const std::string& file : files) {
-        TextBlocks tb(ctx.c, file, g.text_block_bytes);
+        BlockPipe tb(ctx.c, file, g.text_block_bytes);
         if (!tb.ok()) return fatal(tb.error());
         uint8_t lut[256];
         int ab = -1;
