@@ -151,6 +151,34 @@ def convert_vectors(ref, out_dir, manifest):
                                            "note": "a byte below the Solexa minimum: both stderr lines, exit status 255"}
 
 
+def more_vectors(ref, out_dir, manifest):
+    """Further worked examples on the fixture files: the length filters of `seq` seen through `stats`
+    (doc/docs/usage.md:382-392; the documented commands read hairpin.fa from stdin, the file name
+    printed is that of the piped `stats`), the default rows of `fx2tab` (usage.md:786-788, tabs shown
+    expanded) and `stat`, the alias of `stats` (doc/docs/tutorial.md:237-239)."""
+    with open(os.path.join(ref, "doc/docs/usage.md"), encoding="utf-8") as fh:
+        md = fh.read().split("\n")
+    with open(os.path.join(ref, "doc/docs/tutorial.md"), encoding="utf-8") as fh:
+        tut = fh.read().split("\n")
+
+    def put(name, lines, indent, source, argv, mode, note, pipe=None):
+        with open(os.path.join(out_dir, name + ".txt"), "w", encoding="utf-8") as fh:
+            fh.write("".join(l[indent:].rstrip() + "\n" for l in lines))
+        manifest[name] = {"source": source, "argv": argv, "mode": mode, "note": note, "stdin": None}
+        if pipe:
+            manifest[name]["pipe"] = pipe
+
+    for name, cmd_line, flags in (("G16_seq_len_filter_none", 382, []), ("G16_seq_len_filter_m100", 386, ["-m", "100"]),
+                                  ("G16_seq_len_filter_m100_M1000", 390, ["-m", "100", "-M", "1000"])):
+        assert md[cmd_line - 1].split("seqkit seq")[1].split("|")[0].split() == flags
+        put(name, md[cmd_line:cmd_line + 2], 8, "doc/docs/usage.md:%d-%d" % (cmd_line, cmd_line + 2),
+            ["seq", "hairpin.fa.gz"] + flags, "exact", "seq %s | stats" % " ".join(flags), pipe=["stats"])
+    put("G17_fx2tab_default_rows", md[786:788], 8, "doc/docs/usage.md:786-788", ["fx2tab", "hairpin.fa.gz"],
+        "head2_expandtabs", "name, sequence and (empty) quality columns of the first two records")
+    put("G18_stat_alias", tut[237:239], 8, "doc/docs/tutorial.md:237-239", ["stat", "hairpin.fa.gz"], "exact",
+        "`stat` is `stats`")
+
+
 def main(ref):
     out_dir = os.path.join(HERE, "expected")
     os.makedirs(out_dir, exist_ok=True)
@@ -176,6 +204,7 @@ def main(ref):
                                        "note": "record lengths in file order"}
     subseq_vectors(ref, out_dir, manifest)
     convert_vectors(ref, out_dir, manifest)
+    more_vectors(ref, out_dir, manifest)
     with open(os.path.join(out_dir, "manifest.json"), "w") as fh:
         json.dump(manifest, fh, indent=1, sort_keys=True)
     print("wrote %d vectors to %s" % (len(manifest), out_dir))
