@@ -66,6 +66,8 @@ int main(int argc, char **argv)
                         else if (*p == 'n') so.only_name = 1; else if (*p == 's') so.only_seq = 1;
                         else if (*p == 'q') so.only_qual = 1; else if (*p == 'i') so.only_id = 1;
                         else if (*p == 'v') so.validate = 1;
+                        else if (*p == 'g') so.remove_gaps = 1; else if (*p == 'l') so.lower_case = 1;
+                        else if (*p == 'u') so.upper_case = 1;
                         else rc = 1;
                     } else if (is_fx) {
                         if (*p == 'l') fo.length = 1; else if (*p == 'g') fo.gc = 1;
@@ -106,6 +108,12 @@ int main(int argc, char **argv)
             if (is_flag(a, "-i", "--only-id")) { so.only_id = 1; continue; }
             if (is_flag(a, "-v", "--validate-seq")) { so.validate = 1; continue; }
             if (is_flag(a, "-V", "--validate-seq-length")) { so.validate_len = (size_t)atoll(NEXT()); continue; }
+            if (is_flag(a, "-g", "--remove-gaps")) { so.remove_gaps = 1; continue; }
+            if (is_flag(a, "-G", "--gap-letters")) { so.gap_letters = NEXT(); continue; }
+            if (is_flag(a, "-l", "--lower-case")) { so.lower_case = 1; continue; }
+            if (is_flag(a, "-u", "--upper-case")) { so.upper_case = 1; continue; }
+            if (is_flag(a, NULL, "--dna2rna")) { so.dna2rna = 1; continue; }
+            if (is_flag(a, NULL, "--rna2dna")) { so.rna2dna = 1; continue; }
             if (is_flag(a, "-m", "--min-len")) { so.min_len = atoi(NEXT()); continue; }
             if (is_flag(a, "-M", "--max-len")) { so.max_len = atoi(NEXT()); continue; }
         } else if (is_cv) {

@@ -416,10 +416,35 @@ void ora_reader_close(ora_reader *r)
 
 /* ------------------------------------------------------------------ seq */
 /* seqkit/cmd/seq.go:114-280, flags -r -p -n -s -q -i -m -M -w. */
+size_t ora_remove_gaps(uint8_t *seq, uint8_t *qual, size_t len, const char *letters)
+{
+    uint8_t gap[256];
+    memset(gap, 0, sizeof gap);
+    for (const char *p = letters; *p; p++) gap[(uint8_t)*p] = 1;
+    size_t j = 0;
+    for (size_t i = 0; i < len; i++) {
+        if (gap[seq[i]]) continue;
+        seq[j] = seq[i];
+        if (qual) qual[j] = qual[i];
+        j++;
+    }
+    return j;
+}
+
 int ora_cmd_seq(const ora_seq_opts *o, int nfiles, const char **files, FILE *out, FILE *err)
 {
     uint8_t *wrapbuf = NULL; size_t wrapcap = 0;
     int is_fastq = 0, check_type = 1;
+    int once = 1;                                    /* seq.go:107: one "already RNA/DNA" warning per run */
+    const char *gap_letters = o->gap_letters ? o->gap_letters : "- .";
+    /* seq.go:71-78, 96-98 */
+    if (gap_letters[0] == 0) { fprintf(err, "[ERRO] value of flag -G (--gap-letters) should not be empty\n"); return 255; }
+    for (const char *p = gap_letters; *p; p++)
+        if ((uint8_t)*p > 127) { fprintf(err, "[ERRO] value of -G (--gap-letters) contains non-ASCII characters\n"); return 255; }
+    if (o->lower_case && o->upper_case) {
+        fprintf(err, "[ERRO] could not give both flags -l (--lower-case) and -u (--upper-case)\n");
+        return 255;
+    }
     for (int f = 0; f < nfiles; f++) {
         ora_reader *r = ora_reader_open(files[f], o->alphabet, o->guess_len);
         if (!r) { fprintf(err, "[ERRO] open %s: no such file or directory\n", files[f]); return 255; }
@@ -463,6 +488,36 @@ int ora_cmd_seq(const ora_seq_opts *o, int nfiles, const char **files, FILE *out
                 if (ab == ORA_ALPHABET_Protein || ab == ORA_ALPHABET_Unlimit)
                     fprintf(err, "[WARN] Complement does no take effect on protein/unlimit sequence\n");
                 ora_complement_inplace(rec.seq, rec.seq_len, ab);
+            }
+            if (o->remove_gaps) {                                        /* seq.go:196-198 */
+                const size_t kept = ora_remove_gaps(rec.seq, rec.qual_len ? rec.qual : NULL, rec.seq_len, gap_letters);
+                if (rec.qual_len) rec.qual_len = kept;
+                rec.seq_len = kept;
+            }
+            if (ps) {
+                /* seq.go:200-241: only when the sequence is printed; bytes.ToLower / ToUpper on ASCII
+                 * text (bytes beyond 127 are left alone here: parity unpinned) */
+                if (o->dna2rna) {
+                    if (ab == ORA_ALPHABET_RNA || ab == ORA_ALPHABET_RNAredundant) {
+                        if (once) { fprintf(err, "[WARN] it's already RNA, no need to convert\n"); once = 0; }
+                    } else {
+                        for (size_t i = 0; i < rec.seq_len; i++)
+                            if (rec.seq[i] == 't') rec.seq[i] = 'u'; else if (rec.seq[i] == 'T') rec.seq[i] = 'U';
+                    }
+                }
+                if (o->rna2dna) {
+                    if (ab == ORA_ALPHABET_DNA || ab == ORA_ALPHABET_DNAredundant) {
+                        if (once) { fprintf(err, "[WARN] it's already DNA, no need to convert\n"); once = 0; }
+                    } else {
+                        for (size_t i = 0; i < rec.seq_len; i++)
+                            if (rec.seq[i] == 'u') rec.seq[i] = 't'; else if (rec.seq[i] == 'U') rec.seq[i] = 'T';
+                    }
+                }
+                if (o->lower_case) {
+                    for (size_t i = 0; i < rec.seq_len; i++) if (rec.seq[i] >= 'A' && rec.seq[i] <= 'Z') rec.seq[i] += 32;
+                } else if (o->upper_case) {
+                    for (size_t i = 0; i < rec.seq_len; i++) if (rec.seq[i] >= 'a' && rec.seq[i] <= 'z') rec.seq[i] -= 32;
+                }
             }
             size_t need = rec.seq_len + (width > 0 ? rec.seq_len / (size_t)width : 0) + 1;
             if (need > wrapcap) { wrapbuf = (uint8_t *)realloc(wrapbuf, need); wrapcap = need; }

@@ -127,7 +127,17 @@ typedef struct ora_seq_opts {
     size_t guess_len;         /* --alphabet-guess-seq-length (default 10000) */
     int validate;             /* -v, or implied by -t (seq.go:84-93) */
     size_t validate_len;      /* -V: bytes of each record that are checked (default 10000, 0 = all) */
+    int remove_gaps;          /* -g  (seq.go:196-198) */
+    const char *gap_letters;  /* -G  (default "- .", seq.go:298; NULL = default) */
+    int lower_case, upper_case;  /* -l -u (seq.go:236-240) */
+    int dna2rna, rna2dna;     /* --dna2rna --rna2dna (seq.go:201-235) */
 } ora_seq_opts;
+
+/* (*Seq).RemoveGaps(letters) (bio/seq, unpinned module; call site seqkit/cmd/seq.go:197): the
+ * bytes of seq that are in `letters` are dropped, the quality bytes at the same positions with
+ * them (qual may be NULL).  In place; returns the new length.  Pinned for FASTA by the worked
+ * example of doc/docs/usage.md:370-372; what happens to the qualities is parity unpinned. */
+size_t ora_remove_gaps(uint8_t *seq, uint8_t *qual, size_t len, const char *letters);
 int ora_cmd_seq(const ora_seq_opts *o, int nfiles, const char **files, FILE *out, FILE *err);
 
 typedef struct ora_fx2tab_opts {

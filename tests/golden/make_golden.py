@@ -175,6 +175,13 @@ def more_vectors(ref, out_dir, manifest):
             ["seq", "hairpin.fa.gz"] + flags, "exact", "seq %s | stats" % " ".join(flags), pipe=["stats"])
     put("G17_fx2tab_default_rows", md[786:788], 8, "doc/docs/usage.md:786-788", ["fx2tab", "hairpin.fa.gz"],
         "head2_expandtabs", "name, sequence and (empty) quality columns of the first two records")
+    # the transforms behind reverse / complement in the record loop of seq (seq.go:196-241)
+    for name, first, stdin, argv in (("G19_seq_remove_gaps_upper", 371, ">seq\nACGT-ACTGC-ACC\n", ["seq", "-g", "-u"]),
+                                     ("G19_seq_rna2dna", 377, ">seq\nUCAUAUGCUUGUCUCAAAGAUUA\n", ["seq", "--rna2dna"])):
+        assert md[first - 2].strip().endswith("seqkit " + " ".join(argv)), md[first - 2]
+        put(name, md[first - 1:first + 1], 8, "doc/docs/usage.md:%d-%d" % (first - 1, first + 1), argv, "exact",
+            "stdin: " + stdin.replace("\n", "\\n"))
+        manifest[name]["stdin"] = stdin
     put("G18_stat_alias", tut[237:239], 8, "doc/docs/tutorial.md:237-239", ["stat", "hairpin.fa.gz"], "exact",
         "`stat` is `stats`")
 
