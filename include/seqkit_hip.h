@@ -135,6 +135,18 @@ int skh_validate_dev(skh_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_offse
                      uint64_t total_bytes, const uint8_t valid[256], uint64_t limit,
                      skh_validate_result *d_out, void *stream);
 
+/* Gap removal: (*Seq).RemoveGaps(letters) of bio/seq (call site seqkit/cmd/seq.go:196-198, flags
+ * -g / -G at seq.go:297-298).  Every byte b of a record with is_gap[b] != 0 is dropped, and the
+ * quality byte at the same position with it (d_qual may be NULL).  The output is a new batch:
+ * d_out_seq / d_out_qual (room for total_bytes, batch layout rules), d_out_offsets[nrec + 1];
+ * *d_out_bytes (DEVICE memory) = bytes kept.  d_workspace: 256-byte aligned scratch of
+ * skh_remove_gaps_workspace_size(nrec, total_bytes) bytes. */
+uint64_t skh_remove_gaps_workspace_size(uint64_t nrec, uint64_t total_bytes);
+int skh_remove_gaps_dev(skh_ctx *ctx, const uint8_t *d_seq, const uint8_t *d_qual, const uint64_t *d_offsets,
+                        uint64_t nrec, uint64_t total_bytes, const uint8_t is_gap[256], uint8_t *d_out_seq,
+                        uint8_t *d_out_qual, uint64_t *d_out_offsets, void *d_workspace, uint64_t workspace_bytes,
+                        uint64_t *d_out_bytes, void *stream);
+
 /* FASTQ quality re-encoding (`seqkit convert`): seq.QualityConvert(from, to, qual, force)
  * (bio/seq; call sites seqkit/cmd/convert.go:161,245,270) is a per-byte function, so it is
  * handed to the GPU as a 256-entry table: skh_quality_table fills lut (converted byte) and
@@ -380,6 +392,10 @@ int skh_text_names(skh_ctx *ctx, skh_text *t, uint64_t first, uint64_t count, ui
 int skh_text_subseq(skh_ctx *ctx, skh_text *t, const skh_slice *slices, uint64_t n, int64_t start, int64_t end,
                     int minus, const uint8_t *lut, const uint8_t *names, uint64_t names_bytes,
                     const uint64_t *name_pos, const uint32_t *name_len);
+/* skh_remove_gaps_dev on the block (before skh_text_revcomp): afterwards the block's records are
+ * the records without their gap bytes.  The length filter of skh_text_format_seq keeps looking at
+ * the lengths before the removal, as the command does (seq.go:129-134 come before seq.go:196). */
+int skh_text_remove_gaps(skh_ctx *ctx, skh_text *t, const uint8_t is_gap[256]);
 /* skh_stats_dev on the block, merged into *inout. */
 int skh_text_stats(skh_ctx *ctx, skh_text *t, const uint8_t is_gap[256], skh_stats_partial *inout);
 

@@ -86,7 +86,7 @@ int main(int argc, char **argv)
         if (is_flag(a, "-o", "--out-file")) { outfile = NEXT(); continue; }
         if (is_flag(a, "-w", "--line-width")) { so.line_width = atoi(NEXT()); continue; }
         if (is_flag(a, "-j", "--threads")) { (void)NEXT(); continue; }
-        if (is_flag(a, NULL, "--quiet")) continue;
+        if (is_flag(a, NULL, "--quiet")) { so.quiet = 1; continue; }
         if (is_flag(a, NULL, "--alphabet-guess-seq-length")) {
             size_t v = (size_t)atoll(NEXT()); so.guess_len = fo.guess_len = to.guess_len = uo.guess_len = v; continue;
         }

@@ -485,7 +485,7 @@ int ora_cmd_seq(const ora_seq_opts *o, int nfiles, const char **files, FILE *out
             int ab = ora_reader_alphabet(r);
             if (o->reverse) ora_reverse_inplace(rec.seq, rec.qual_len ? rec.qual : NULL, rec.seq_len);
             if (o->complement) {
-                if (ab == ORA_ALPHABET_Protein || ab == ORA_ALPHABET_Unlimit)
+                if ((!o->quiet && ab == ORA_ALPHABET_Protein) || ab == ORA_ALPHABET_Unlimit)     /* once per record */
                     fprintf(err, "[WARN] Complement does no take effect on protein/unlimit sequence\n");
                 ora_complement_inplace(rec.seq, rec.seq_len, ab);
             }

@@ -131,6 +131,8 @@ typedef struct ora_seq_opts {
     const char *gap_letters;  /* -G  (default "- .", seq.go:298; NULL = default) */
     int lower_case, upper_case;  /* -l -u (seq.go:236-240) */
     int dna2rna, rna2dna;     /* --dna2rna --rna2dna (seq.go:201-235) */
+    int quiet;                /* --quiet: silences the complement warning for Protein only (seq.go:191 reads
+                               * `!config.Quiet && alphabet == Protein || alphabet == Unlimit`) */
 } ora_seq_opts;
 
 /* (*Seq).RemoveGaps(letters) (bio/seq, unpinned module; call site seqkit/cmd/seq.go:197): the

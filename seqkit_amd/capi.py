@@ -116,6 +116,9 @@ SYMBOLS = {
     "skh_text_format_seq_submit": (C.c_int, [vp, vp, C.POINTER(SeqFormat)]),
     "skh_text_format_tab_submit": (C.c_int, [vp, vp, C.POINTER(TabFormat)]),
     "skh_text_output_wait": (C.c_int, [vp, vp, C.POINTER(vp), u64p]),
+    "skh_remove_gaps_workspace_size": (C.c_uint64, [C.c_uint64, C.c_uint64]),
+    "skh_remove_gaps_dev": (C.c_int, [vp, vp, vp, vp, C.c_uint64, C.c_uint64, u8p, vp, vp, vp, vp, C.c_uint64, vp, vp]),
+    "skh_text_remove_gaps": (C.c_int, [vp, vp, u8p]),
     "skh_text_stats": (C.c_int, [vp, vp, u8p, C.POINTER(StatsPartial)]),
     "skh_batch_alloc": (C.c_int, [vp, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(vp)]),
     "skh_batch_free": (None, [vp]),

@@ -8,6 +8,7 @@
 #include <math.h>
 
 #include <atomic>
+#include <utility>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -378,6 +379,37 @@ int skh_stats_dev(skh_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_offsets,
     return SKH_OK;
 }
 
+uint64_t skh_remove_gaps_workspace_size(uint64_t nrec, uint64_t total_bytes)
+{
+    return skh::remove_gaps_workspace_size(nrec, total_bytes);
+}
+
+int skh_remove_gaps_dev(skh_ctx* ctx, const uint8_t* d_seq, const uint8_t* d_qual, const uint64_t* d_offsets, uint64_t nrec,
+                        uint64_t total_bytes, const uint8_t is_gap[256], uint8_t* d_out_seq, uint8_t* d_out_qual,
+                        uint64_t* d_out_offsets, void* d_workspace, uint64_t workspace_bytes, uint64_t* d_out_bytes,
+                        void* stream)
+{
+    if (!ctx) return fail(SKH_EINVAL, "ctx is NULL");
+    if (!is_gap || !d_out_offsets || !d_out_bytes || !d_workspace) return fail(SKH_EINVAL, "NULL argument");
+    int rc = check_plane_args(d_seq, d_offsets, nrec, total_bytes);
+    if (rc) return rc;
+    if (total_bytes != 0 && !d_out_seq) return fail(SKH_EINVAL, "output plane is NULL");
+    if (d_qual && !d_out_qual) return fail(SKH_EINVAL, "quality plane given without an output plane for it");
+    if (reinterpret_cast<uintptr_t>(d_qual) & 15) return fail(SKH_EINVAL, "quality plane is not 16-byte aligned");
+    if (reinterpret_cast<uintptr_t>(d_workspace) & 255) return fail(SKH_EINVAL, "workspace is not 256-byte aligned");
+    if (workspace_bytes < skh::remove_gaps_workspace_size(nrec, total_bytes))
+        return fail(SKH_ECAPACITY, "workspace smaller than skh_remove_gaps_workspace_size(nrec, total_bytes)");
+    skh::Table256 t;
+    for (int b = 0; b < 256; b++) t.v[b] = is_gap[b] ? 1 : 0;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    uint32_t* flag = next_flag(ctx);
+    HIP_TRY(hipMemsetAsync(flag, 0, sizeof(uint32_t), st));
+    HIP_TRY(skh::launch_remove_gaps(cfg_for(ctx, nrec, total_bytes), d_seq, d_qual, d_offsets, nrec, total_bytes, t, d_out_seq,
+                                    d_out_qual, d_out_offsets, d_workspace, d_out_bytes, flag, st));
+    return SKH_OK;
+}
+
 int skh_validate_dev(skh_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_offsets, uint64_t nrec, uint64_t total_bytes,
                      const uint8_t valid[256], uint64_t limit, skh_validate_result* d_out, void* stream)
 {
@@ -460,7 +492,7 @@ int skh_parse_dev(skh_ctx* ctx, const uint8_t* d_text, uint64_t text_bytes, int 
 
 uint64_t skh_format_workspace_size(uint64_t nrec) { return skh::format_workspace_size(nrec); }
 
-int skh_format_seq_dev(skh_ctx* ctx, const uint8_t* d_text, const uint64_t* d_name_pos, const uint32_t* d_name_len,
+static int format_seq_impl(skh_ctx* ctx, const uint64_t* d_filter_offsets, const uint8_t* d_text, const uint64_t* d_name_pos, const uint32_t* d_name_len,
                        const uint8_t* d_seq, const uint8_t* d_qual, const uint64_t* d_offsets, uint64_t nrec,
                        const skh_seq_format* fmt, uint8_t* d_out, uint64_t out_capacity, void* d_workspace,
                        uint64_t workspace_bytes, skh_format_result* d_result, void* stream)
@@ -479,7 +511,7 @@ int skh_format_seq_dev(skh_ctx* ctx, const uint8_t* d_text, const uint64_t* d_na
         return fail(SKH_ECAPACITY, "workspace smaller than skh_format_workspace_size(nrec)");
     skh::FormatSeqArgs a;
     a.text = d_text; a.name_pos = d_name_pos; a.name_len = d_name_len; a.seq = d_seq; a.qual = d_qual;
-    a.offsets = d_offsets; a.nrec = nrec; a.min_len = fmt->min_len; a.max_len = fmt->max_len;
+    a.offsets = d_offsets; a.filter_offsets = d_filter_offsets; a.nrec = nrec; a.min_len = fmt->min_len; a.max_len = fmt->max_len;
     a.width = (uint32_t)fmt->line_width;
     a.print_name = fmt->print_name != 0; a.print_seq = fmt->print_seq != 0; a.print_qual = fmt->print_qual != 0;
     a.plus_line = fmt->plus_line != 0; a.only_id = fmt->only_id != 0; a.mark = (uint8_t)fmt->mark;
@@ -488,6 +520,15 @@ int skh_format_seq_dev(skh_ctx* ctx, const uint8_t* d_text, const uint64_t* d_na
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
     HIP_TRY(skh::launch_format_seq(a, d_out, out_capacity, d_workspace, reinterpret_cast<skh::FormatResult*>(d_result), st));
     return SKH_OK;
+}
+
+int skh_format_seq_dev(skh_ctx* ctx, const uint8_t* d_text, const uint64_t* d_name_pos, const uint32_t* d_name_len,
+                       const uint8_t* d_seq, const uint8_t* d_qual, const uint64_t* d_offsets, uint64_t nrec,
+                       const skh_seq_format* fmt, uint8_t* d_out, uint64_t out_capacity, void* d_workspace,
+                       uint64_t workspace_bytes, skh_format_result* d_result, void* stream)
+{
+    return format_seq_impl(ctx, nullptr, d_text, d_name_pos, d_name_len, d_seq, d_qual, d_offsets, nrec, fmt, d_out, out_capacity,
+                           d_workspace, workspace_bytes, d_result, stream);
 }
 
 int skh_format_tab_dev(skh_ctx* ctx, const uint8_t* d_text, const uint64_t* d_name_pos, const uint32_t* d_name_len,
@@ -779,6 +820,10 @@ struct skh_text {
     int fastq = 0;
     uint64_t nrec = 0, seq_bytes = 0, text_bytes = 0;
     uint64_t text_off = 0;                  // where the parsed text starts in h_text (skh_text_parse_at)
+    uint64_t* d_goffs = nullptr;            // skh_text_remove_gaps: offsets after the removal
+    void* d_gws = nullptr;
+    uint64_t goffs_cap = 0, gws_bytes = 0;
+    const uint64_t* filter_offs = nullptr;  // lengths the -m / -M filter of the formatter looks at (nullptr: v_offs)
     uint64_t out_pending = 0;               // bytes of h_out on their way (skh_text_format_*_submit)
     uint8_t* d_stage = nullptr;             // skh_text_upload: device copy of h_text at the same offsets
     uint64_t up_off = 0, up_bytes = 0;      // the range uploaded ahead of the next parse (up_bytes = 0: none)
@@ -789,6 +834,7 @@ struct skh_text {
     const uint8_t* v_text = nullptr;
     // skh_text_subseq: slice list, offsets and names of the result
     uint64_t plane_cap = 0;                 // bytes of d_seq2 / d_qual2
+    uint64_t base_cap = 0;                  // bytes of d_seq / d_qual
     skh::Slice* d_slices = nullptr;
     uint64_t *d_offs2 = nullptr, *d_npos2 = nullptr;
     uint32_t* d_nlen2 = nullptr;
@@ -853,6 +899,7 @@ int skh_text_alloc(skh_ctx* ctx, uint64_t block_bytes, skh_text** out)
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&t->d_seq2), t->cap);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&t->d_qual2), t->cap);
     t->plane_cap = t->cap;
+    t->base_cap = t->cap;
     if (e == hipSuccess) e = hipHostMalloc(&t->h_res, 256, hipHostMallocDefault);
     if (e == hipSuccess) e = hipMalloc(&t->d_res, 256);
     if (e == hipSuccess) e = text_alloc_lines(t, t->cap / 32 + 1024);
@@ -872,7 +919,7 @@ void skh_text_free(skh_text* t)
     (void)hipSetDevice(t->ctx->device);
     if (t->stream) { (void)hipStreamSynchronize(t->stream); (void)hipStreamDestroy(t->stream); }
     text_free_lines(t);
-    (void)hipFree(t->d_stage);
+    (void)hipFree(t->d_stage); (void)hipFree(t->d_goffs); (void)hipFree(t->d_gws);
     (void)hipFree(t->d_text); (void)hipFree(t->d_seq); (void)hipFree(t->d_qual); (void)hipFree(t->d_seq2); (void)hipFree(t->d_qual2);
     (void)hipFree(t->d_out); (void)hipFree(t->d_res);
     (void)hipFree(t->d_slices); (void)hipFree(t->d_offs2); (void)hipFree(t->d_npos2); (void)hipFree(t->d_nlen2);
@@ -936,6 +983,7 @@ int skh_text_parse_at(skh_ctx* ctx, skh_text* t, uint64_t text_offset, uint64_t 
     t->text_bytes = text_bytes;
     t->transformed = false;
     t->v_offs = t->d_offs; t->v_npos = t->d_npos; t->v_nlen = t->d_nlen; t->v_text = t->d_text;
+    t->filter_offs = nullptr;
     return SKH_OK;
 }
 
@@ -978,11 +1026,11 @@ int skh_text_revcomp(skh_ctx* ctx, skh_text* t, const uint8_t* lut, int do_rever
     if (!ctx || !t) return fail(SKH_EINVAL, "NULL argument");
     if (t->transformed) return fail(SKH_EINVAL, "block was already transformed");
     if (t->nrec == 0 || (!lut && !do_reverse)) return SKH_OK;
-    int rc = skh_revcomp_dev(ctx, t->d_seq, t->d_seq2, t->d_offs, t->nrec, t->seq_bytes, lut, do_reverse, t->stream);
+    int rc = skh_revcomp_dev(ctx, t->d_seq, t->d_seq2, t->v_offs, t->nrec, t->seq_bytes, lut, do_reverse, t->stream);
     if (rc) return rc;
     if (t->fastq) {
         if (do_reverse && reverse_qual)
-            rc = skh_revcomp_dev(ctx, t->d_qual, t->d_qual2, t->d_offs, t->nrec, t->seq_bytes, nullptr, 1, t->stream);
+            rc = skh_revcomp_dev(ctx, t->d_qual, t->d_qual2, t->v_offs, t->nrec, t->seq_bytes, nullptr, 1, t->stream);
         else
             HIP_TRY(hipMemcpyAsync(t->d_qual2, t->d_qual, t->seq_bytes, hipMemcpyDeviceToDevice, t->stream));
         if (rc) return rc;
@@ -1028,9 +1076,9 @@ int skh_text_format_seq_submit(skh_ctx* ctx, skh_text* t, const skh_seq_format* 
     const uint8_t* qual = t->fastq ? (t->transformed ? t->d_qual2 : t->d_qual) : nullptr;
     if (fmt->print_qual && !qual) return fail(SKH_EINVAL, "quality requested for a FASTA block");
     for (;;) {
-        int rc = skh_format_seq_dev(ctx, t->v_text, t->v_npos, t->v_nlen, seq, qual, t->v_offs, t->nrec, fmt, t->d_out,
-                                    t->out_cap, t->d_fws, t->fws_bytes, static_cast<skh_format_result*>(t->d_res),
-                                    t->stream);
+        int rc = format_seq_impl(ctx, t->filter_offs, t->v_text, t->v_npos, t->v_nlen, seq, qual, t->v_offs, t->nrec, fmt, t->d_out,
+                                 t->out_cap, t->d_fws, t->fws_bytes, static_cast<skh_format_result*>(t->d_res),
+                                 t->stream);
         if (rc) return rc;
         HIP_TRY(hipMemcpyAsync(t->h_res, t->d_res, sizeof(skh_format_result), hipMemcpyDeviceToHost, t->stream));
         HIP_TRY(hipStreamSynchronize(t->stream));
@@ -1168,7 +1216,7 @@ int skh_text_map_quality(skh_ctx* ctx, skh_text* t, const uint8_t lut[256])
     if (t->transformed) return fail(SKH_EINVAL, "block was already transformed");
     if (t->nrec == 0) return SKH_OK;
     HIP_TRY(hipSetDevice(ctx->device));
-    int rc = skh_revcomp_dev(ctx, t->d_qual, t->d_qual2, t->d_offs, t->nrec, t->seq_bytes, lut, 0, t->stream);
+    int rc = skh_revcomp_dev(ctx, t->d_qual, t->d_qual2, t->v_offs, t->nrec, t->seq_bytes, lut, 0, t->stream);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(t->d_seq2, t->d_seq, t->seq_bytes, hipMemcpyDeviceToDevice, t->stream));
     t->transformed = true;
@@ -1257,6 +1305,43 @@ int skh_text_subseq(skh_ctx* ctx, skh_text* t, const skh_slice* slices, uint64_t
         t->fws_bytes = skh::format_workspace_size(t->fws_records);
         HIP_TRY(hipMalloc(&t->d_fws, t->fws_bytes));
     }
+    return SKH_OK;
+}
+
+int skh_text_remove_gaps(skh_ctx* ctx, skh_text* t, const uint8_t is_gap[256])
+{
+    if (!ctx || !t || !is_gap) return fail(SKH_EINVAL, "NULL argument");
+    if (t->transformed) return fail(SKH_EINVAL, "block was already transformed");
+    if (t->v_offs != t->d_offs) return fail(SKH_EINVAL, "gaps were already removed from this block");
+    if (t->nrec == 0) return SKH_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (t->nrec + 1 > t->goffs_cap) {
+        (void)hipFree(t->d_goffs); t->d_goffs = nullptr; t->goffs_cap = 0;
+        const uint64_t cap = t->nrec + t->nrec / 4 + 1024;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&t->d_goffs), cap * 8));
+        t->goffs_cap = cap;
+    }
+    const uint64_t need = skh::remove_gaps_workspace_size(t->nrec, t->seq_bytes);
+    if (need > t->gws_bytes) {
+        (void)hipFree(t->d_gws); t->d_gws = nullptr; t->gws_bytes = 0;
+        HIP_TRY(hipMalloc(&t->d_gws, need + need / 4));
+        t->gws_bytes = need + need / 4;
+    }
+    int rc = skh_remove_gaps_dev(ctx, t->d_seq, t->fastq ? t->d_qual : nullptr, t->d_offs, t->nrec, t->seq_bytes, is_gap,
+                                 t->d_seq2, t->fastq ? t->d_qual2 : nullptr, t->d_goffs, t->d_gws, t->gws_bytes,
+                                 static_cast<uint64_t*>(t->d_res), t->stream);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(t->h_res, t->d_res, 8, hipMemcpyDeviceToHost, t->stream));
+    HIP_TRY(hipStreamSynchronize(t->stream));
+    // the compacted planes become the block's planes (the two pairs of buffers change places: both
+    // hold at least a block of text); the lengths before the removal stay available to the formatter,
+    // whose length filter looks at the records as they were read (seq.go:129-134 come before :196)
+    std::swap(t->d_seq, t->d_seq2);
+    std::swap(t->d_qual, t->d_qual2);
+    std::swap(t->base_cap, t->plane_cap);
+    t->seq_bytes = *static_cast<uint64_t*>(t->h_res);
+    t->v_offs = t->d_goffs;
+    t->filter_offs = t->d_offs;
     return SKH_OK;
 }
 

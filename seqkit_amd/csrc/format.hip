@@ -42,7 +42,8 @@ __global__ __launch_bounds__(FB) void k_fmt_sizes(const FormatSeqArgs a, uint64_
 {
     for (uint64_t r = (uint64_t)blockIdx.x * FB + threadIdx.x; r < a.nrec; r += (uint64_t)gridDim.x * FB) {
         const uint64_t len = a.offsets[r + 1] - a.offsets[r];
-        const bool keep = !(a.min_len >= 0 && len < (uint64_t)a.min_len) && !(a.max_len >= 0 && len > (uint64_t)a.max_len);
+        const uint64_t flen = a.filter_offsets ? a.filter_offsets[r + 1] - a.filter_offsets[r] : len;
+        const bool keep = !(a.min_len >= 0 && flen < (uint64_t)a.min_len) && !(a.max_len >= 0 && flen > (uint64_t)a.max_len);
         if (keep && len > SKH_LONG_T && (a.print_seq || a.print_qual)) atomicAdd(n_long, 1u);
         uint32_t nl = 0;
         uint64_t sz = 0;

@@ -72,6 +72,7 @@ struct FormatSeqArgs {
     const uint8_t* seq;
     const uint8_t* qual;          // only read when print_qual
     const uint64_t* offsets;
+    const uint64_t* filter_offsets;   // lengths the min_len / max_len filter looks at (nullptr: offsets)
     uint64_t nrec;
     int64_t min_len, max_len;     // < 0 = no limit
     uint32_t width;               // line width of sequence and quality (0 = no wrapping)
@@ -109,6 +110,15 @@ hipError_t launch_format_seq(const FormatSeqArgs& a, uint8_t* out, uint64_t out_
 // `part` holds scan64_partials(n) values of scratch.
 uint64_t scan64_partials(uint64_t n);
 hipError_t launch_scan64(const uint64_t* v, uint64_t n, uint64_t* out, uint64_t* part, uint64_t* total, hipStream_t s);
+
+// ---- gap removal (gaps.hip) -------------------------------------------------------------------
+
+uint64_t remove_gaps_workspace_size(uint64_t nrec, uint64_t total);
+// out planes need room for `total` bytes; out_offs nrec + 1 entries; *result = bytes kept.  n_long:
+// a zeroed flag word for the counting pass.
+hipError_t launch_remove_gaps(const LaunchCfg& cfg, const uint8_t* seq, const uint8_t* qual, const uint64_t* offs,
+                              uint64_t nrec, uint64_t total, const Table256& is_gap, uint8_t* out_seq, uint8_t* out_qual,
+                              uint64_t* out_offs, void* workspace, uint64_t* result, uint32_t* n_long, hipStream_t s);
 
 // ---- subsequences (slices.hip) --------------------------------------------------------------
 

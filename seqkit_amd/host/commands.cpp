@@ -595,12 +595,13 @@ int first_record_alphabet(skh_ctx* ctx, skh_text* t, const GlobalOpts& g, int fo
 int seq_text_path(const GlobalOpts& g, const SeqOpts& o, const std::vector<std::string>& files, skh_ctx* ctx, Sink& out)
 {
     bool is_fastq = false, check_type = true;        // seq.go:105-106: decided once, by the first printed record
+    bool warn_once = true;                           // seq.go:107: one "already RNA / DNA" warning per run
     std::vector<uint64_t> offs;
     for (const std::string& file : files) {
         BlockPipe tb(ctx, file, g.text_block_bytes);
         if (!tb.ok()) return fatal(tb.error());
-        uint8_t lut[256], valid[256];
-        bool lut_ready = false;
+        uint8_t lut[256], valid[256], gap_pre[256];
+        bool lut_ready = false, any_map = false;
         int ab = -1;                                  // the file's alphabet: -t, or guessed from its first record
         std::string pending_error;                    // an invalid record: reported after the records before it
         skh_parse_result res;
@@ -623,7 +624,7 @@ int seq_text_path(const GlobalOpts& g, const SeqOpts& o, const std::vector<std::
         auto one_block = [&]() -> int {
             skh_text* t = tb.block();
             if (res.nrec == 0) { tb.advance(res); return 0; }
-            if (ab < 0 && (o.complement || o.validate)) {
+            if (ab < 0 && (o.complement || o.validate || o.dna2rna || o.rna2dna)) {
                 std::string err;
                 ab = first_record_alphabet(ctx, t, g, g.alphabet, err);
                 if (ab < 0) return fatal(err);
@@ -647,19 +648,43 @@ int seq_text_path(const GlobalOpts& g, const SeqOpts& o, const std::vector<std::
                     if (res.nrec == 0) return 0;
                 }
             }
-            if (o.complement && !lut_ready) {
-                if (!g.quiet && (ab == Protein || ab == Unlimit))
-                    fprintf(stderr, "[WARN] Complement does no take effect on protein/unlimit sequence\n");
-                skh_pair_table(ab, lut);
+            if (!lut_ready) {
+                // One table for everything seq.go:190-241 does to a base: complement, then (when the
+                // sequence is printed) T -> U or U -> T, then the case.  Gaps are removed before the table
+                // is applied, so the gap test asks what the complement of a byte is.
+                uint8_t comp[256];
+                for (int b = 0; b < 256; b++) comp[b] = (uint8_t)b;
+                if (o.complement) skh_pair_table(ab, comp);
+                const bool shown = !(o.only_name && !o.only_seq) && !(o.only_qual && !o.only_seq && !o.only_name);
+                bool to_rna = false, to_dna = false;
+                if (shown && o.dna2rna) {
+                    if (ab == RNA || ab == RNAredundant) {
+                        if (warn_once) { fprintf(stderr, "[WARN] it's already RNA, no need to convert\n"); warn_once = false; }
+                    } else to_rna = true;
+                }
+                if (shown && o.rna2dna) {
+                    if (ab == DNA || ab == DNAredundant) {
+                        if (warn_once) { fprintf(stderr, "[WARN] it's already DNA, no need to convert\n"); warn_once = false; }
+                    } else to_dna = true;
+                }
+                any_map = o.complement;
+                for (int b = 0; b < 256; b++) {
+                    uint8_t c = comp[b];
+                    if (to_rna) c = c == 't' ? 'u' : c == 'T' ? 'U' : c;
+                    if (to_dna) c = c == 'u' ? 't' : c == 'U' ? 'T' : c;
+                    if (shown && o.lower_case && c >= 'A' && c <= 'Z') c = (uint8_t)(c + 32);
+                    else if (shown && o.upper_case && c >= 'a' && c <= 'z') c = (uint8_t)(c - 32);
+                    lut[b] = c;
+                    if (c != (uint8_t)b) any_map = true;
+                    gap_pre[b] = 0;
+                }
+                for (unsigned char gl : o.gap_letters)
+                    for (int b = 0; b < 256; b++) if (comp[b] == gl) gap_pre[b] = 1;
                 lut_ready = true;
-            }
-            if (o.reverse || o.complement) {
-                // seq.go:187-195: ReverseInplace (bases and qualities), then ComplementInplace
-                PhaseTimer pt(2);
-                if (skh_text_revcomp(ctx, t, o.complement ? lut : nullptr, o.reverse, 1) != SKH_OK) return fatal(skh_last_error());
             }
             if (check_type) {
                 // the first record that passes the length filters decides how everything is printed
+                // (seq.go:140-145: looked at as the record was read)
                 offs.resize(res.nrec + 1);
                 if (skh_text_offsets(ctx, t, 0, res.nrec + 1, offs.data()) != SKH_OK) return fatal(skh_last_error());
                 for (uint64_t r = 0; r < res.nrec && check_type; r++) {
@@ -669,6 +694,28 @@ int seq_text_path(const GlobalOpts& g, const SeqOpts& o, const std::vector<std::
                     is_fastq = tb.is_fastq() && len > 0;
                     check_type = false;
                 }
+            }
+            if (o.complement && ((!g.quiet && ab == Protein) || ab == Unlimit)) {
+                // seq.go:190-193: one warning per record that gets as far as the complement (the condition
+                // reads `!config.Quiet && alphabet == Protein || alphabet == Unlimit`)
+                offs.resize(res.nrec + 1);
+                if (skh_text_offsets(ctx, t, 0, res.nrec + 1, offs.data()) != SKH_OK) return fatal(skh_last_error());
+                for (uint64_t r = 0; r < res.nrec; r++) {
+                    const uint64_t len = offs[r + 1] - offs[r];
+                    if (o.min_len >= 0 && len < (uint64_t)o.min_len) continue;
+                    if (o.max_len >= 0 && len > (uint64_t)o.max_len) continue;
+                    fprintf(stderr, "[WARN] Complement does no take effect on protein/unlimit sequence\n");
+                }
+            }
+            if (o.remove_gaps) {
+                // seq.go:196-198 (the byte-wise table commutes with dropping bytes and with the reversal)
+                PhaseTimer pt(2);
+                if (skh_text_remove_gaps(ctx, t, gap_pre) != SKH_OK) return fatal(skh_last_error());
+            }
+            if (o.reverse || any_map) {
+                // seq.go:187-195: ReverseInplace (bases and qualities), then ComplementInplace
+                PhaseTimer pt(2);
+                if (skh_text_revcomp(ctx, t, any_map ? lut : nullptr, o.reverse, 1) != SKH_OK) return fatal(skh_last_error());
             }
             if (!check_type) {
                 skh_seq_format f;
@@ -719,6 +766,8 @@ int cmd_seq(const GlobalOpts& g, const SeqOpts& o, const std::vector<std::string
     Sink out(g.out_file);
     if (!out.ok()) return fatal("open " + g.out_file + ": cannot create");
     if (!g.host_parse) return seq_text_path(g, o, files, ctx.c, out);
+    if (o.remove_gaps || o.lower_case || o.upper_case || o.dna2rna || o.rna2dna)
+        return fatal("--host-parse does not know -g, -l, -u, --dna2rna, --rna2dna (they are done on the GPU text path)");
     bool is_fastq = false, check_type = true;        // seq.go:105-106: decided once, by the first record
     TwoBatches tb;
 
@@ -726,7 +775,7 @@ int cmd_seq(const GlobalOpts& g, const SeqOpts& o, const std::vector<std::string
         FastxReader rd(ctx.c, file, g.alphabet, g.guess_len);
         if (!rd.ok()) return fatal(rd.error());
         uint8_t lut[256];
-        bool lut_ready = false, warned = false;
+        bool lut_ready = false;
 
         // prints a finished batch (seq.go:163-276)
         auto emit = [&](Batch& bt) -> int {
@@ -786,13 +835,18 @@ int cmd_seq(const GlobalOpts& g, const SeqOpts& o, const std::vector<std::string
             }
             if (got) {
                 if (o.complement && !lut_ready) {
-                    const int ab = rd.alphabet();
-                    if (!g.quiet && (ab == Protein || ab == Unlimit) && !warned) {
-                        fprintf(stderr, "[WARN] Complement does no take effect on protein/unlimit sequence\n");
-                        warned = true;
-                    }
-                    skh_pair_table(ab, lut);
+                    skh_pair_table(rd.alphabet(), lut);
                     lut_ready = true;
+                }
+                if (o.complement && ((!g.quiet && rd.alphabet() == Protein) || rd.alphabet() == Unlimit)) {
+                    // seq.go:190-193: one warning per record that gets as far as the complement
+                    const uint64_t* off = bt.offs();
+                    for (uint64_t r = 0; r < bt.nrec; r++) {
+                        const uint64_t len = off[r + 1] - off[r];
+                        if (o.min_len >= 0 && len < (uint64_t)o.min_len) continue;
+                        if (o.max_len >= 0 && len > (uint64_t)o.max_len) continue;
+                        fprintf(stderr, "[WARN] Complement does no take effect on protein/unlimit sequence\n");
+                    }
                 }
                 if (o.reverse || o.complement) {
                     // seq.go:187-195: ReverseInplace (bases and qualities), then ComplementInplace

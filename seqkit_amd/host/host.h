@@ -106,7 +106,9 @@ struct GlobalOpts {
 struct SeqOpts { bool reverse = false, complement = false, only_name = false, only_seq = false,
                  only_qual = false, only_id = false; int min_len = -1, max_len = -1;
                  bool validate = false;            // -v, or implied by -t (seq.go:84-93)
-                 uint64_t validate_len = 10000; }; // -V: bytes of each record that are checked (0 = all)
+                 uint64_t validate_len = 10000;    // -V: bytes of each record that are checked (0 = all)
+                 bool remove_gaps = false; std::string gap_letters = "- .";     // -g -G (seq.go:196-198)
+                 bool lower_case = false, upper_case = false, dna2rna = false, rna2dna = false; };   // seq.go:200-241
 struct Fx2tabOpts { bool only_id = false, length = false, gc = false, gc_skew = false, only_name = false,
                     header_line = false, alphabet_col = false; std::vector<std::string> base; };
 struct StatsOpts { bool all = false, tabular = false; std::string gap_letters = "- ."; };

@@ -89,7 +89,8 @@ int usage()
 {
     fprintf(stderr,
             "seqkit-hip -- SeqKit's seq / fx2tab / stats with the per-record work on an AMD MI355X\n\n"
-            "Usage:\n  seqkit-hip seq    [-r] [-p] [-n] [-s] [-q] [-i] [-m N] [-M N] [global flags] [files...]\n"
+            "Usage:\n  seqkit-hip seq    [-r] [-p] [-g] [-G letters] [--dna2rna] [--rna2dna] [-l] [-u] [-n] [-s] [-q] [-i]\n"
+            "                    [-m N] [-M N] [-v] [-V N] [global flags] [files...]\n"
             "  seqkit-hip fx2tab [-l] [-g] [-G] [-B bases]... [-n] [-i] [-H] [-a] [global flags] [files...]\n"
             "  seqkit-hip stats  [-a] [-T] [-G gap-letters] [global flags] [files...]\n"
             "  seqkit-hip subseq [-r start:end | --gtf FILE | --bed FILE] [--chr IDs] [--feature types] [--gtf-tag TAG]\n"
@@ -119,8 +120,10 @@ int main(int argc, char** argv)
     if (is_seq) {
         const Flag f[] = {{"r", "reverse", false}, {"p", "complement", false}, {"n", "name", false}, {"s", "seq", false},
                           {"q", "qual", false}, {"i", "only-id", false}, {"m", "min-len", true}, {"M", "max-len", true},
-                          {"v", "validate-seq", false}, {"V", "validate-seq-length", true}};
-        p.flags.insert(p.flags.end(), f, f + 10);
+                          {"v", "validate-seq", false}, {"V", "validate-seq-length", true},
+                          {"g", "remove-gaps", false}, {"G", "gap-letters", true}, {"l", "lower-case", false},
+                          {"u", "upper-case", false}, {nullptr, "dna2rna", false}, {nullptr, "rna2dna", false}};
+        p.flags.insert(p.flags.end(), f, f + 16);
     } else if (is_cv) {
         const Flag f[] = {{nullptr, "from", true}, {nullptr, "to", true}, {"d", "dry-run", false}, {"f", "force", false},
                           {"n", "nrecords", true}, {"N", "thresh-B-in-n-most-common", true},
@@ -174,6 +177,12 @@ int main(int argc, char** argv)
         o.max_len = atoi(p.value("max-len", "-1").c_str());
         if (o.min_len >= 0 && o.max_len >= 0 && o.min_len > o.max_len)
             return fatal("value of flag -m (--min-len) should be >= value of flag -M (--max-len)");
+        o.remove_gaps = p.has("remove-gaps"); o.gap_letters = p.value("gap-letters", "- .");
+        o.lower_case = p.has("lower-case"); o.upper_case = p.has("upper-case");
+        o.dna2rna = p.has("dna2rna"); o.rna2dna = p.has("rna2dna");
+        if (o.gap_letters.empty()) return fatal("value of flag -G (--gap-letters) should not be empty");         // seq.go:71-78
+        for (unsigned char c : o.gap_letters)
+            if (c > 127) return fatal("value of -G (--gap-letters) contains non-ASCII characters");
         o.validate = p.has("validate-seq");
         const long long vl = atoll(p.value("validate-seq-length", "10000").c_str());
         if (vl < 0) return fatal("value of flag --validate-seq-length should be greater than 0");
@@ -183,6 +192,8 @@ int main(int argc, char** argv)
             fprintf(stderr, "[INFO] when flag -t (--seq-type) given, flag -v (--validate-seq) is automatically switched on\n");
             o.validate = true;
         }
+        if (o.lower_case && o.upper_case)                                   // seq.go:96-98
+            return fatal("could not give both flags -l (--lower-case) and -u (--upper-case)");
         return cmd_seq(g, o, files);
     }
     if (is_cv) {

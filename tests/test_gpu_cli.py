@@ -205,6 +205,45 @@ def test_long_lines_and_long_reads(cli, oracle_cli, tmp_path):
     assert got[0] == want[0] == 0 and got[1] == want[1]
 
 
+SEQ_EDIT_FLAGS = [["-g"], ["-g", "-u"], ["-g", "-G", "N-"], ["-r", "-p", "-g"], ["-l"], ["-u", "-r"], ["--dna2rna"],
+                  ["--rna2dna"], ["--rna2dna", "-p", "-u"], ["--dna2rna", "-s", "-w", "0"], ["-g", "-m", "100", "-M", "160"],
+                  ["-g", "-G", "ACGTUacgtu", "-m", "60"], ["-g", "-q"], ["-l", "-n"], ["-g", "-r", "-p", "-l", "--dna2rna"]]
+
+
+@pytest.mark.parametrize("flags", SEQ_EDIT_FLAGS, ids=lambda v: " ".join(v))
+def test_seq_gaps_conversions_and_case(cli, oracle_cli, flags, tmp_path):
+    # the transforms behind reverse / complement in seq's record loop (seq.go:196-241)
+    import numpy as np
+    rng = np.random.default_rng(31)
+    gapped = tmp_path / "gapped.fa"
+    with open(gapped, "wb") as fh:
+        for i, n in enumerate([70, 0, 150, 33000, 5, 1200, 160, 99, 100, 101]):
+            s = rng.choice(np.frombuffer(b"ACGTacgtNn-. -UuRY", np.uint8), size=n).tobytes()
+            fh.write(b">g%d with gaps\n" % i)
+            for a in range(0, max(n, 1), 60):
+                fh.write(s[a:a + 60] + b"\n")
+    gq = tmp_path / "gapped.fq"
+    with open(gq, "wb") as fh:
+        for i, n in enumerate([70, 150, 40000, 5, 99, 100]):
+            s = rng.choice(np.frombuffer(b"ACGTN-.", np.uint8), size=n).tobytes()
+            q = rng.integers(33, 74, size=n, dtype=np.uint8).tobytes()
+            fh.write(b"@q%d\n" % i + s + b"\n+\n" + q + b"\n")
+    for f in ("hairpin.fa.gz", "reads_1.fq.gz", str(gapped), str(gq)):
+        if "-q" in flags and not f.endswith(("fq", "fq.gz")):
+            continue
+        for extra in ([], ["--batch-bytes", "30000"]):
+            want = run_cli(oracle_cli, ["seq"] + flags + [f])
+            got = run_cli(cli, ["seq"] + flags + extra + [f])
+            assert got[0] == want[0] == 0 and got[1] == want[1] and got[2] == want[2], (f, flags, extra)
+
+
+def test_seq_edit_flag_errors(cli, oracle_cli):
+    for argv in (["seq", "-l", "-u", "contigs.fa"], ["seq", "-g", "-G", "", "contigs.fa"]):
+        want = run_cli(oracle_cli, argv)
+        got = run_cli(cli, argv)
+        assert got[0] == want[0] == 255 and got[2] == want[2] and got[1] == b""
+
+
 def test_large_output_to_regular_files(cli, oracle_cli, tmp_path):
     # tens of megabytes of output into regular files: -o, stdout redirected to a file that already
     # holds text, and a file opened for appending

@@ -30,6 +30,17 @@ def subseq(a, b, minus):
                               p(sub_offs), C.c_void_p(sub_ws), sub_wsb, p(sub_res), sp)
 
 
+gap_offs = torch.empty(nrec + 1, dtype=torch.int64, device=dev)
+gap_wsb = lib.skh_remove_gaps_workspace_size(nrec, total)
+gap_ws_t = torch.empty(gap_wsb + 256, dtype=torch.uint8, device=dev); gap_ws = (gap_ws_t.data_ptr() + 255) & ~255
+gap_n = (C.c_uint8 * 256)(); gap_n[ord("N")] = 1; gap_n[ord("-")] = 1
+
+
+def remove_gaps(with_qual):
+    return lib.skh_remove_gaps_dev(ctx, p(seq), p(qual) if with_qual else None, p(offs), nrec, total, gap_n, p(so),
+                                   p(qo) if with_qual else None, p(gap_offs), C.c_void_p(gap_ws), gap_wsb, p(sub_res), sp)
+
+
 torch.cuda.synchronize()   # data was generated on the default stream
 st = torch.cuda.Stream(device=dev); sp = C.c_void_p(st.cuda_stream)
 p = lambda t: C.c_void_p(t.data_ptr())
@@ -46,6 +57,8 @@ cases = {
     "subseq -r 13:-13 (2B/out base+16B/rec)": (lambda: subseq(13, -13, 0), 2 * (L - 24) * nrec + 16 * nrec),
     "subseq -r 1:-1 minus strand (2B/base+16B/rec)": (lambda: subseq(1, -1, 1), 2 * total + 16 * nrec),
     "subseq -r 1:12 (2B/out base+16B/rec)": (lambda: subseq(1, 12, 0), 2 * 12 * nrec + 16 * nrec),
+    "remove gaps, bases only (3B/base+24B/rec)": (lambda: remove_gaps(False), 3 * total + 24 * nrec),
+    "remove gaps, bases + qualities (6B/base+24B/rec)": (lambda: remove_gaps(True), 6 * total + 24 * nrec),
     "stats (1B/base+8B/rec)": (lambda: lib.skh_stats_dev(ctx, p(seq), p(offs), nrec, total, gap, p(stats), sp), total + 8 * nrec),
 }
 with torch.cuda.stream(st):
