@@ -301,9 +301,17 @@ typedef struct skh_tab_column {
 } skh_tab_column;
 typedef struct skh_tab_format {
     uint32_t ncols;
-    uint8_t only_id, print_seq, print_qual, reserved;
+    uint8_t only_id, print_seq, print_qual;
+    uint8_t alphabet;              /* != 0: a last column with the byte values present in the record, ascending
+                                    * (alphabetStr, fx2tab.go:145-147,167-180), read from d_letters */
     skh_tab_column cols[SKH_TAB_MAX_COLS];
+    const uint32_t *d_letters;     /* DEVICE memory, nrec x 8 words from skh_letters_dev; the text-block form
+                                    * fills it in from skh_text_letters */
 } skh_tab_format;
+/* Which byte values occur in each record: d_present[r * 8 + (b >> 5)] has bit (b & 31) set when byte
+ * value b occurs in record r (the set alphabetStr builds with a map, fx2tab.go:167-180). */
+int skh_letters_dev(skh_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_offsets, uint64_t nrec,
+                    uint64_t total_bytes, uint32_t *d_present, void *stream);
 int skh_format_tab_dev(skh_ctx *ctx, const uint8_t *d_text, const uint64_t *d_name_pos,
                        const uint32_t *d_name_len, const uint8_t *d_seq, const uint8_t *d_qual,
                        const uint64_t *d_offsets, uint64_t nrec,
@@ -363,6 +371,8 @@ int skh_text_output_wait(skh_ctx *ctx, skh_text *t, const uint8_t **out, uint64_
 /* skh_count_dev on the block; the counts stay on the device in slot `pass`
  * (< SKH_TAB_MAX_PASSES) for skh_text_format_tab. */
 int skh_text_count(skh_ctx *ctx, skh_text *t, const uint8_t class_of[256], uint32_t nclass, uint32_t pass);
+/* skh_letters_dev on the block; the result stays on the device for skh_text_format_tab (fmt->alphabet). */
+int skh_text_letters(skh_ctx *ctx, skh_text *t);
 /* skh_format_tab_dev on the block with the counts of the passes run so far + download. */
 int skh_text_format_tab(skh_ctx *ctx, skh_text *t, const skh_tab_format *fmt,
                         const uint8_t **out, uint64_t *out_bytes);

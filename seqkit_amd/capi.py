@@ -37,7 +37,7 @@ class TabColumn(C.Structure):
 
 class TabFormat(C.Structure):
     _fields_ = [("ncols", C.c_uint32), ("only_id", C.c_uint8), ("print_seq", C.c_uint8), ("print_qual", C.c_uint8),
-                ("reserved", C.c_uint8), ("cols", TabColumn * 16)]
+                ("alphabet", C.c_uint8), ("cols", TabColumn * 16), ("d_letters", C.c_void_p)]
 
 
 TAB_LENGTH, TAB_GC, TAB_GC_SKEW, TAB_CONTENT = 0, 1, 2, 3
@@ -119,6 +119,8 @@ SYMBOLS = {
     "skh_remove_gaps_workspace_size": (C.c_uint64, [C.c_uint64, C.c_uint64]),
     "skh_remove_gaps_dev": (C.c_int, [vp, vp, vp, vp, C.c_uint64, C.c_uint64, u8p, vp, vp, vp, vp, C.c_uint64, vp, vp]),
     "skh_text_remove_gaps": (C.c_int, [vp, vp, u8p]),
+    "skh_letters_dev": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_uint64, vp, vp]),
+    "skh_text_letters": (C.c_int, [vp, vp]),
     "skh_text_stats": (C.c_int, [vp, vp, u8p, C.POINTER(StatsPartial)]),
     "skh_batch_alloc": (C.c_int, [vp, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(vp)]),
     "skh_batch_free": (None, [vp]),

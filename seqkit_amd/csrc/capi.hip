@@ -379,6 +379,22 @@ int skh_stats_dev(skh_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_offsets,
     return SKH_OK;
 }
 
+int skh_letters_dev(skh_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_offsets, uint64_t nrec, uint64_t total_bytes,
+                    uint32_t* d_present, void* stream)
+{
+    if (!ctx) return fail(SKH_EINVAL, "ctx is NULL");
+    int rc = check_plane_args(d_seq, d_offsets, nrec, total_bytes);
+    if (rc) return rc;
+    if (nrec == 0) return SKH_OK;
+    if (!d_present) return fail(SKH_EINVAL, "output pointer is NULL");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    uint32_t* flag = next_flag(ctx);
+    HIP_TRY(hipMemsetAsync(flag, 0, sizeof(uint32_t), st));
+    HIP_TRY(skh::launch_letters(cfg_for(ctx, nrec, total_bytes), d_seq, d_offsets, nrec, total_bytes, d_present, flag, st));
+    return SKH_OK;
+}
+
 uint64_t skh_remove_gaps_workspace_size(uint64_t nrec, uint64_t total_bytes)
 {
     return skh::remove_gaps_workspace_size(nrec, total_bytes);
@@ -555,6 +571,8 @@ int skh_format_tab_dev(skh_ctx* ctx, const uint8_t* d_text, const uint64_t* d_na
     a.offsets = d_offsets; a.nrec = nrec;
     for (int p = 0; p < SKH_TAB_MAX_PASSES; p++) { a.counts[p] = d_counts[p]; a.nclass[p] = nclass[p]; }
     a.ncols = fmt->ncols;
+    if (fmt->alphabet && nrec != 0 && !fmt->d_letters) return fail(SKH_EINVAL, "alphabet column requested without d_letters");
+    a.letters = fmt->alphabet ? fmt->d_letters : nullptr;
     a.only_id = fmt->only_id != 0; a.print_seq = fmt->print_seq != 0; a.print_qual = fmt->print_qual != 0;
     for (uint32_t c = 0; c < fmt->ncols; c++) {
         const skh_tab_column& col = fmt->cols[c];
@@ -820,6 +838,9 @@ struct skh_text {
     int fastq = 0;
     uint64_t nrec = 0, seq_bytes = 0, text_bytes = 0;
     uint64_t text_off = 0;                  // where the parsed text starts in h_text (skh_text_parse_at)
+    uint32_t* d_letters = nullptr;          // skh_text_letters: nrec x 8 words
+    uint64_t letters_cap = 0;
+    bool letters_ready = false;
     uint64_t* d_goffs = nullptr;            // skh_text_remove_gaps: offsets after the removal
     void* d_gws = nullptr;
     uint64_t goffs_cap = 0, gws_bytes = 0;
@@ -919,7 +940,7 @@ void skh_text_free(skh_text* t)
     (void)hipSetDevice(t->ctx->device);
     if (t->stream) { (void)hipStreamSynchronize(t->stream); (void)hipStreamDestroy(t->stream); }
     text_free_lines(t);
-    (void)hipFree(t->d_stage); (void)hipFree(t->d_goffs); (void)hipFree(t->d_gws);
+    (void)hipFree(t->d_stage); (void)hipFree(t->d_goffs); (void)hipFree(t->d_gws); (void)hipFree(t->d_letters);
     (void)hipFree(t->d_text); (void)hipFree(t->d_seq); (void)hipFree(t->d_qual); (void)hipFree(t->d_seq2); (void)hipFree(t->d_qual2);
     (void)hipFree(t->d_out); (void)hipFree(t->d_res);
     (void)hipFree(t->d_slices); (void)hipFree(t->d_offs2); (void)hipFree(t->d_npos2); (void)hipFree(t->d_nlen2);
@@ -984,6 +1005,7 @@ int skh_text_parse_at(skh_ctx* ctx, skh_text* t, uint64_t text_offset, uint64_t 
     t->transformed = false;
     t->v_offs = t->d_offs; t->v_npos = t->d_npos; t->v_nlen = t->d_nlen; t->v_text = t->d_text;
     t->filter_offs = nullptr;
+    t->letters_ready = false;
     return SKH_OK;
 }
 
@@ -1121,6 +1143,13 @@ int skh_text_format_tab_submit(skh_ctx* ctx, skh_text* t, const skh_tab_format* 
     const uint8_t* seq = t->transformed ? t->d_seq2 : t->d_seq;
     const uint8_t* qual = t->fastq ? (t->transformed ? t->d_qual2 : t->d_qual) : nullptr;
     if (fmt->print_qual && !qual) return fail(SKH_EINVAL, "quality requested for a FASTA block");
+    skh_tab_format with_letters;
+    if (fmt->alphabet) {
+        if (!t->letters_ready) return fail(SKH_EINVAL, "alphabet column requested before skh_text_letters");
+        with_letters = *fmt;
+        with_letters.d_letters = t->d_letters;
+        fmt = &with_letters;
+    }
     for (;;) {
         int rc = skh_format_tab_dev(ctx, t->v_text, t->v_npos, t->v_nlen, seq, qual, t->v_offs, t->nrec, t->d_counts,
                                     t->nclass, fmt, t->d_out, t->out_cap, t->d_fws, t->fws_bytes,
@@ -1306,6 +1335,21 @@ int skh_text_subseq(skh_ctx* ctx, skh_text* t, const skh_slice* slices, uint64_t
         HIP_TRY(hipMalloc(&t->d_fws, t->fws_bytes));
     }
     return SKH_OK;
+}
+
+int skh_text_letters(skh_ctx* ctx, skh_text* t)
+{
+    if (!ctx || !t) return fail(SKH_EINVAL, "NULL argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const uint64_t need = (t->nrec ? t->nrec : 1) * 8;
+    if (need > t->letters_cap) {
+        (void)hipFree(t->d_letters); t->d_letters = nullptr; t->letters_cap = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&t->d_letters), (need + need / 4) * 4));
+        t->letters_cap = need + need / 4;
+    }
+    t->letters_ready = true;
+    if (t->nrec == 0) return SKH_OK;
+    return skh_letters_dev(ctx, t->transformed ? t->d_seq2 : t->d_seq, t->v_offs, t->nrec, t->seq_bytes, t->d_letters, t->stream);
 }
 
 int skh_text_remove_gaps(skh_ctx* ctx, skh_text* t, const uint8_t is_gap[256])

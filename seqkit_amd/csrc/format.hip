@@ -352,7 +352,13 @@ __global__ __launch_bounds__(FB) void k_tab_sizes(const FormatTabArgs a, uint64_
         if (a.only_id) nl = id_length(a.text + a.name_pos[r], nl);
         char buf[TAB_NUM_MAX];
         const uint32_t nn = tab_numbers(a, r, len, buf);
-        size[r] = (uint64_t)nl + 1 + (a.print_seq ? len : 0) + 1 + (a.print_qual ? len : 0) + nn + 1;
+        uint32_t na = 0;                                  // alphabet column: a tab and the letters present
+        if (a.letters) {
+            na = 1;
+#pragma unroll
+            for (int i = 0; i < 8; i++) na += (uint32_t)__builtin_popcount(a.letters[r * 8 + i]);
+        }
+        size[r] = (uint64_t)nl + 1 + (a.print_seq ? len : 0) + 1 + (a.print_qual ? len : 0) + nn + na + 1;
         shown_name[r] = nl;
     }
 }
@@ -424,7 +430,19 @@ __global__ __launch_bounds__(FB) void k_tab_numbers(const FormatTabArgs a, const
         char buf[TAB_NUM_MAX];
         const uint32_t nn = tab_numbers(a, r, len, buf);
         for (uint32_t k = 0; k < nn; k++) o[k] = (uint8_t)buf[k];
-        o[nn] = '\n';
+        o += nn;
+        if (a.letters) {                                  // fx2tab.go:145-147: the byte values present, ascending
+            *o++ = '\t';
+            for (uint32_t i = 0; i < 8; i++) {
+                uint32_t w = a.letters[r * 8 + i];
+                while (w) {
+                    const uint32_t bit = (uint32_t)__builtin_ctz(w);
+                    *o++ = (uint8_t)(32 * i + bit);
+                    w &= w - 1;
+                }
+            }
+        }
+        *o = '\n';
     }
 }
 

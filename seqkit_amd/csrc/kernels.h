@@ -35,6 +35,9 @@ hipError_t launch_map_plane(const LaunchCfg& cfg, const uint8_t* in, uint8_t* ou
 hipError_t launch_count(const LaunchCfg& cfg, const uint8_t* seq, const uint64_t* offs, uint64_t nrec,
                         uint64_t total, const Table256& cls, uint32_t nclass, uint32_t neutral,
                         uint64_t* counts, uint32_t* n_long, hipStream_t st);
+// present: nrec x 8 words, bit (b & 31) of word (b >> 5) set when byte value b occurs in the record
+hipError_t launch_letters(const LaunchCfg& cfg, const uint8_t* seq, const uint64_t* offs, uint64_t nrec, uint64_t total,
+                          uint32_t* present, uint32_t* n_long, hipStream_t st);
 hipError_t launch_stats(const LaunchCfg& cfg, const uint8_t* seq, const uint64_t* offs, uint64_t nrec,
                         uint64_t total, const Table256& is_gap, StatsPartial* out, hipStream_t st);
 
@@ -95,6 +98,7 @@ struct FormatTabArgs {
     const uint8_t* seq; const uint8_t* qual; const uint64_t* offsets; uint64_t nrec;
     const uint64_t* counts[TAB_MAX_PASSES];    // per counting pass: nrec x nclass[pass]
     uint32_t nclass[TAB_MAX_PASSES];
+    const uint32_t* letters;                   // alphabet column: nrec x 8 words from launch_letters (nullptr: no column)
     uint32_t ncols;
     uint8_t only_id, print_seq, print_qual, pad;
     TabColumn cols[TAB_MAX_COLS];

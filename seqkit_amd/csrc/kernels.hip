@@ -1099,6 +1099,118 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_count_tiles(
     }
 }
 
+// ------------------------------------------------------------------ letters present
+//
+// Which byte values occur in each record: 256 bits per record (8 words; bit b & 31 of word b >> 5).
+// The alphabet column of fx2tab (alphabetStr, seqkit/cmd/fx2tab.go:167-180) prints the set bits in
+// ascending order.  Same decomposition as the counting kernels: lane groups for records up to
+// LONG_T bytes, aligned windows of the plane with one atomic OR per word for longer ones.
+
+__device__ __forceinline__ void set_bits16(uint4 v, int lo, int hi, uint32_t* m)
+{
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        if (k >= lo && k < hi) {
+            const uint32_t b = (w[k >> 2] >> (8 * (k & 3))) & 0xffu;
+            const uint32_t bit = 1u << (b & 31u), wi = b >> 5;
+#pragma unroll
+            for (int i = 0; i < 8; i++) m[i] |= wi == (uint32_t)i ? bit : 0u;
+        }
+    }
+}
+
+__global__ __launch_bounds__(SKH_BLOCK) void k_letters_short(const uint8_t* __restrict__ seq,
+                                                             const uint64_t* __restrict__ offs, uint64_t nrec,
+                                                             uint64_t total, int logG, uint32_t* __restrict__ present,
+                                                             uint32_t* __restrict__ n_long)
+{
+    const uint32_t G = 1u << logG, j = threadIdx.x & (G - 1);
+    const uint32_t lane = threadIdx.x & 63, GW = 64u >> logG, g = lane >> logG;
+    const uint64_t stride = (uint64_t)gridDim.x * (SKH_BLOCK / 64) * GW;
+    for (uint64_t rec0 = ((uint64_t)blockIdx.x * (SKH_BLOCK / 64) + (threadIdx.x >> 6)) * GW; rec0 < nrec; rec0 += stride) {
+        WaveOffsets wo;
+        wo.load(offs, nrec, total, rec0, GW, lane);
+        const uint64_t rec = rec0 + g;
+        const uint64_t s = wo.get(g + 1, GW), e = wo.get(g + 2, GW);
+        const uint64_t len = e - s;
+        uint32_t m[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) m[i] = 0;
+        if (len > SKH_LONG_T) {
+            if (j == 0) atomicAdd(n_long, 1u);       // k_letters_tiles ORs into the zeros written here
+        } else if (len != 0) {
+            const uint64_t o0 = s & ~15ull;
+            const uint32_t K = (uint32_t)((e - o0 + 15) >> 4);
+            for (uint32_t k = j; k < K; k += G) {
+                const uint64_t o = o0 + 16ull * k;
+                const int lo = s > o ? (int)(s - o) : 0;
+                const int hi = e < o + 16 ? (int)(e - o) : 16;
+                set_bits16(ld16(seq + o), lo, hi, m);
+            }
+            for (uint32_t d = 1; d < G; d <<= 1) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) m[i] |= __shfl_xor(m[i], d);
+            }
+        }
+        if (rec < nrec) {
+            for (uint32_t i = j; i < 8; i += G) {
+                uint32_t v = m[0];
+#pragma unroll
+                for (int q = 1; q < 8; q++) v = i == (uint32_t)q ? m[q] : v;
+                present[rec * 8 + i] = v;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(SKH_BLOCK) void k_letters_tiles(const uint8_t* __restrict__ seq,
+                                                             const uint64_t* __restrict__ offs, uint64_t nrec,
+                                                             uint64_t total, uint32_t* __restrict__ present,
+                                                             const uint32_t* __restrict__ n_long)
+{
+    if (*n_long == 0) return;
+    __shared__ uint32_t s_m[8];
+    const uint64_t ntiles = (total + SKH_TILE - 1) / SKH_TILE;
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint64_t t0 = tile * SKH_TILE;
+        const uint64_t t1 = t0 + SKH_TILE;
+        const uint64_t last = (t1 < total ? t1 : total) - 1;
+        const uint64_t r_lo = find_record(offs, nrec, t0);
+        const uint64_t r_hi = find_record(offs, nrec, last);
+#pragma unroll 1
+        for (int c = 0; c < 2; c++) {
+            if (c == 1 && r_hi == r_lo) break;
+            const uint64_t r = c == 0 ? r_lo : r_hi;
+            const uint64_t s = offs[r], e = offs[r + 1];
+            if (e - s <= SKH_LONG_T) continue;                 // block-uniform
+            const uint64_t a = s & ~15ull, b = (e + 15) & ~15ull;
+            const uint64_t c0 = a > t0 ? a : t0, c1 = b < t1 ? b : t1;
+            uint32_t m[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) m[i] = 0;
+            for (uint64_t o = c0 + 16ull * threadIdx.x; o < c1; o += 16ull * SKH_BLOCK) {
+                const int lo = s > o ? (int)(s - o) : 0;
+                const int hi = e < o + 16 ? (int)(e - o) : 16;
+                set_bits16(ld16(seq + o), lo, hi, m);
+            }
+            for (uint32_t d = 1; d < 64; d <<= 1) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) m[i] |= __shfl_xor(m[i], d);
+            }
+            __syncthreads();                                   // s_m free again
+            if (threadIdx.x < 8) s_m[threadIdx.x] = 0;
+            __syncthreads();
+            if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) if (m[i]) atomicOr(&s_m[i], m[i]);
+            }
+            __syncthreads();
+            if (threadIdx.x < 8 && s_m[threadIdx.x]) atomicOr(&present[r * 8 + threadIdx.x], s_m[threadIdx.x]);
+        }
+    }
+}
+
 // ------------------------------------------------------------------ stats totals
 
 __global__ void k_stats_init(StatsPartial* out, uint64_t nrec, uint64_t total)
@@ -1384,6 +1496,16 @@ hipError_t launch_count(const LaunchCfg& cfg, const uint8_t* seq, const uint64_t
         hipLaunchKernelGGL((k_count_tiles<2>), dim3(g2), dim3(SKH_BLOCK), 0, st, seq, offs, nrec, total,
                            cls, nclass, neutral, counts, n_long);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_letters(const LaunchCfg& cfg, const uint8_t* seq, const uint64_t* offs, uint64_t nrec, uint64_t total,
+                          uint32_t* present, uint32_t* n_long, hipStream_t st)
+{
+    const uint32_t g1 = grid_for(nrec, SKH_BLOCK >> cfg.logG, cfg.n_cu * 8);
+    hipLaunchKernelGGL(k_letters_short, dim3(g1), dim3(SKH_BLOCK), 0, st, seq, offs, nrec, total, cfg.logG, present, n_long);
+    const uint32_t g2 = grid_for((total + SKH_TILE - 1) / SKH_TILE, 1, cfg.n_cu * 8);
+    hipLaunchKernelGGL(k_letters_tiles, dim3(g2), dim3(SKH_BLOCK), 0, st, seq, offs, nrec, total, present, n_long);
     return hipGetLastError();
 }
 

@@ -922,8 +922,8 @@ int cmd_fx2tab(const GlobalOpts& g, const Fx2tabOpts& o, const std::vector<std::
     }
 
     // Rows built on the GPU from file text parsed on the GPU, whenever the request fits the
-    // device formatter (everything but the alphabet column and very long letter lists).
-    bool device_rows = !g.host_parse && !o.alphabet_col && npass <= SKH_TAB_MAX_PASSES;
+    // device formatter (everything but very long letter lists).
+    bool device_rows = !g.host_parse && npass <= SKH_TAB_MAX_PASSES;
     skh_tab_format tf;
     memset(&tf, 0, sizeof tf);
     if (device_rows) {
@@ -970,6 +970,11 @@ int cmd_fx2tab(const GlobalOpts& g, const Fx2tabOpts& o, const std::vector<std::
                         if (skh_text_count(ctx.c, t, pass_table[ps].data(), pass_nclass[ps], (uint32_t)ps) != SKH_OK)
                             return fatal(skh_last_error());
                 }
+                if (o.alphabet_col) {                          // fx2tab.go:145-147
+                    PhaseTimer pt(2);
+                    if (skh_text_letters(ctx.c, t) != SKH_OK) return fatal(skh_last_error());
+                }
+                tf.alphabet = o.alphabet_col ? 1 : 0;
                 tf.print_seq = !o.only_name;
                 tf.print_qual = !o.only_name && tb.is_fastq();
                 {

@@ -130,6 +130,23 @@ def test_fx2tab_small_blocks(cli, oracle_cli):
         assert got[0] == 0 and got[1] == want[1]
 
 
+@pytest.mark.parametrize("flags", [["-a"], ["-n", "-i", "-a"], ["-n", "-l", "-g", "-B", "AT", "-a", "-H"]], ids=lambda v: " ".join(v))
+def test_fx2tab_alphabet_column(cli, oracle_cli, flags, tmp_path):
+    # fx2tab.go:145-147,167-180: the byte values present in each record, ascending (GPU rows)
+    import numpy as np
+    rng = np.random.default_rng(41)
+    odd = tmp_path / "odd.fa"
+    with open(odd, "wb") as fh:
+        for i, n in enumerate([50, 0, 1, 40000, 300, 33000]):
+            s = rng.choice(np.frombuffer(bytes(c for c in range(33, 127) if c != ord(">")), np.uint8), size=n).tobytes()
+            fh.write(b">o%d\n" % i + s + b"\n")
+    for f in FILES + [str(odd)]:
+        for extra in ([], ["--batch-bytes", "50000"]):
+            want = run_cli(oracle_cli, ["fx2tab"] + flags + [f])
+            got = run_cli(cli, ["fx2tab"] + flags + extra + [f])
+            assert got[0] == want[0] == 0 and got[1] == want[1], (f, flags, extra)
+
+
 def test_fx2tab_float_trap(cli):
     # 34/160 + 33/160 prints 41.87 (two divisions, seqkit/cmd/fx2tab.go:128-133), not 41.88
     _, out, _ = run_cli(cli, ["fx2tab", "-n", "-i", "-l", "-g", "hairpin.fa.gz"])

@@ -117,3 +117,27 @@ def test_remove_gaps_at_bench_size(lib, ctx):
     assert torch.equal(out[:int(res[0])], seq[keep])
     want_offs = torch.cat([torch.zeros(1, dtype=torch.int64, device="cuda:0"), keep.view(nrec, L).sum(1).cumsum(0)])
     assert torch.equal(noffs, want_offs)
+
+
+# ---------------------------------------------------------------- letters present per record (fx2tab -a)
+
+def letters_of(seq, offs):
+    out = np.zeros((len(offs) - 1, 8), np.uint32)
+    for r in range(len(offs) - 1):
+        for b in np.unique(seq[int(offs[r]):int(offs[r + 1])]):
+            out[r, int(b) >> 5] |= np.uint32(1 << (int(b) & 31))
+    return out
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_letters_present_matches_numpy(lib, ctx, case):
+    import torch
+    seq, _, offs = make_batch(CASES[case], seed=len(case), letters=bytes(range(1, 256)))
+    nrec, total = len(offs) - 1, int(offs[-1])
+    d_seq, d_offs = to_dev(seq), to_dev(offs)
+    d_p = torch.full((nrec * 8,), -1, dtype=torch.int32, device="cuda:0")
+    torch.cuda.synchronize()
+    lib.check(lib.skh_letters_dev(ctx, ptr(d_seq), ptr(d_offs), nrec, total, ptr(d_p), None))
+    lib.check(lib.skh_sync(ctx))
+    got = d_p.cpu().numpy().view(np.uint32).reshape(nrec, 8)
+    assert np.array_equal(got, letters_of(seq, offs))
