@@ -24,11 +24,13 @@
 
 namespace host {
 
+void drop_cached_blocks();          // text blocks kept between the files of a command (BlockPipe)
+
 namespace {
 
 struct Ctx {
     skh_ctx* c = nullptr;
-    ~Ctx() { if (c) skh_destroy(c); }
+    ~Ctx() { drop_cached_blocks(); if (c) skh_destroy(c); }
 };
 
 struct TwoBatches {
@@ -235,6 +237,7 @@ class BlockPipe {
         bool eof = false;                // the file ended in (or right after) this block
         bool grown = false;              // enlarged for long records: half of it is headroom
         bool head_line = false;          // FASTA: what the reader put in holds a line that starts with '>'
+        uint64_t ordinary_for = 0;       // the block size it was allocated for (0: enlarged); such blocks are kept for the next file
         skh_parse_result res;
     };
     // a queue of block pointers; nullptr from pop() means "closed and empty"
@@ -270,9 +273,37 @@ class BlockPipe {
     // tail is less than one record), half of a block that was enlarged for records longer than that.
     static uint64_t headroom(const Block& b) { return ((b.grown ? b.cap / 2 : b.cap / 8)) & ~uint64_t(4095); }
 
+    // Blocks of the ordinary size outlive their file: the next file of the command takes them over
+    // instead of pinning fresh memory (a few milliseconds per block).
+    struct Cache { std::mutex mu; std::vector<Block*> blocks; };
+    static Cache& cache() { static Cache c; return c; }
+
+public:
+    static void drop_cache()
+    {
+        Cache& c = cache();
+        std::lock_guard<std::mutex> l(c.mu);
+        for (Block* b : c.blocks) { skh_text_free(b->t); delete b; }
+        c.blocks.clear();
+    }
+
+private:
     static Block* new_block(State& s, uint64_t cap, bool grown)
     {
+        if (!grown) {
+            Cache& c = cache();
+            std::lock_guard<std::mutex> l(c.mu);
+            for (size_t k = 0; k < c.blocks.size(); k++) {
+                if (c.blocks[k]->ordinary_for != cap) continue;
+                Block* b = c.blocks[k];
+                c.blocks.erase(c.blocks.begin() + (long)k);
+                b->head = headroom(*b);
+                b->filled = 0; b->eof = false; b->head_line = false;
+                return b;
+            }
+        }
         Block* b = new Block;
+        b->ordinary_for = grown ? 0 : cap;
         PhaseTimer pt(5);
         if (skh_text_alloc(s.ctx, cap, &b->t) != SKH_OK) { s.fail(skh_last_error()); delete b; return nullptr; }
         b->cap = skh_text_capacity(b->t);
@@ -538,7 +569,15 @@ public:
         }
         if (leave) return;
         PhaseTimer pt(5);
-        for (Block* b : s.all) { if (b->t) skh_text_free(b->t); delete b; }
+        for (Block* b : s.all) {
+            if (b->ordinary_for) {
+                Cache& c = cache();
+                std::lock_guard<std::mutex> l(c.mu);
+                if (c.blocks.size() < 4) { c.blocks.push_back(b); continue; }
+            }
+            if (b->t) skh_text_free(b->t);
+            delete b;
+        }
         s.all.clear();
         if (s.fh) gzclose((gzFile)s.fh);
         if (s.fd >= 0) close(s.fd);
@@ -577,6 +616,10 @@ private:
     Block* cur_ = nullptr;
     bool regular_ = false;
 };
+
+}  // namespace
+void drop_cached_blocks() { BlockPipe::drop_cache(); }
+namespace {
 
 // alphabet of a file as the reference's reader guesses it: from the first record
 int first_record_alphabet(skh_ctx* ctx, skh_text* t, const GlobalOpts& g, int forced, std::string& err)
