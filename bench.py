@@ -332,7 +332,10 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, L, lut, cls)
         if not args.no_e2e and world == 1:
             torch.cuda.synchronize()
-            out["end_to_end"] = end_to_end(nrec, L, seq, qual)
+            try:
+                out["end_to_end"] = end_to_end(nrec, L, seq, qual)
+            except (OSError, subprocess.SubprocessError) as exc:      # e.g. no room for the file: the line still counts
+                out["end_to_end"] = {"value": None, "error": str(exc)}
         print(json.dumps(out), flush=True)
     lib.skh_destroy(ctx)
     if world > 1:
