@@ -15,6 +15,7 @@ struct StatsPartial { int64_t num, len_sum, gap_sum, len_min, len_max; };
 
 struct LaunchCfg {
     int logG;            // log2 of lanes per record in the short kernels (0..6)
+    int logG_count;      // the same for the counting kernel (a lane takes more chunks there)
     uint32_t max_grid;   // optional cap on workgroups of a grid-stride launch (0 = none)
     uint32_t n_cu;       // compute units of the device
     int staged;          // reverse, short records: 1 = LDS-staged kernel, 0 = direct (lane exchange) kernel

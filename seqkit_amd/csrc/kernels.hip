@@ -1480,19 +1480,19 @@ hipError_t launch_count(const LaunchCfg& cfg, const uint8_t* seq, const uint64_t
 {
     const uint64_t ntile = (total + SKH_TILE - 1) / SKH_TILE;
     const uint32_t steps = cfg.count_steps ? cfg.count_steps : 4;     // steps per wavefront
-    const uint64_t per_block = (uint64_t)steps * (SKH_BLOCK >> cfg.logG);
+    const uint64_t per_block = (uint64_t)steps * (SKH_BLOCK >> cfg.logG_count);
     const uint64_t g1 = (nrec + per_block - 1) / per_block;
     if (g1 > 0x7fffffffull) return hipErrorInvalidValue;
     if (nclass <= 4) {
         const uint32_t g2 = grid_for(ntile, 1, resident_cap(k_count_tiles<1>, cfg));
         hipLaunchKernelGGL((k_count_short<1>), dim3((uint32_t)g1), dim3(SKH_BLOCK), 0, st, seq, offs, nrec, total,
-                           cls, nclass, cfg.logG, steps, neutral, counts, n_long);
+                           cls, nclass, cfg.logG_count, steps, neutral, counts, n_long);
         hipLaunchKernelGGL((k_count_tiles<1>), dim3(g2), dim3(SKH_BLOCK), 0, st, seq, offs, nrec, total,
                            cls, nclass, neutral, counts, n_long);
     } else {
         const uint32_t g2 = grid_for(ntile, 1, resident_cap(k_count_tiles<2>, cfg));
         hipLaunchKernelGGL((k_count_short<2>), dim3((uint32_t)g1), dim3(SKH_BLOCK), 0, st, seq, offs, nrec, total,
-                           cls, nclass, cfg.logG, steps, neutral, counts, n_long);
+                           cls, nclass, cfg.logG_count, steps, neutral, counts, n_long);
         hipLaunchKernelGGL((k_count_tiles<2>), dim3(g2), dim3(SKH_BLOCK), 0, st, seq, offs, nrec, total,
                            cls, nclass, neutral, counts, n_long);
     }
