@@ -121,17 +121,20 @@ __global__ __launch_bounds__(FB) void k_scan_apply64(const uint64_t* __restrict_
 
 // ---- cooperative writers (G lanes of one record) --------------------------------------------
 
+__device__ __forceinline__ void copy16(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src)
+{
+    uint4 v;
+    __builtin_memcpy(&v, src, 16);
+    __builtin_memcpy(dst, &v, 16);
+}
+
 template <uint32_t G>
 __device__ __forceinline__ void copy_plain(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, uint64_t n, uint32_t j)
 {
     for (uint64_t p = (uint64_t)j * 16; p < n; p += G * 16) {
-        if (p + 16 <= n) {
-            uint4 v;
-            __builtin_memcpy(&v, src + p, 16);
-            __builtin_memcpy(dst + p, &v, 16);
-        } else {
-            for (uint64_t k = p; k < n; k++) dst[k] = src[k];
-        }
+        if (p + 16 <= n) copy16(dst + p, src + p);
+        else if (n >= 16) copy16(dst + n - 16, src + n - 16);     // the last 16 bytes again: same values, no byte loop
+        else for (uint64_t k = p; k < n; k++) dst[k] = src[k];
     }
 }
 
@@ -145,9 +148,14 @@ __device__ __forceinline__ void copy_wrapped(uint8_t* __restrict__ dst, const ui
         const uint64_t last = p + 16 <= n ? p + 15 : n - 1;
         const uint64_t l0 = p / width, l1 = last / width;
         if (l0 == l1 && p + 16 <= n) {
-            uint4 v;
-            __builtin_memcpy(&v, src + p, 16);
-            __builtin_memcpy(dst + p + l0, &v, 16);
+            copy16(dst + p + l0, src + p);
+        } else if (l1 == l0 + 1 && width >= 16 && (l0 + 1) * (uint64_t)width >= 16 && (l0 + 1) * (uint64_t)width + 16 <= n) {
+            // the chunk straddles one line break: the 16 bytes that end the line and the 16 bytes that
+            // start the next one, each as one copy (what they overlap of the neighbour chunks has the
+            // same values)
+            const uint64_t b = (l0 + 1) * (uint64_t)width;          // first base of the next line
+            copy16(dst + b - 16 + l0, src + b - 16);
+            copy16(dst + b + l1, src + b);
         } else {
             for (uint64_t k = p; k <= last; k++) dst[k + k / width] = src[k];
         }

@@ -482,12 +482,17 @@ __global__ __launch_bounds__(PB) void k_parse_copy(const ParseState* st, uint64_
     const uint32_t j = threadIdx.x & (G - 1);
     const uint64_t nrec = st->nrec, nlines = st->nlines;
     if (st->status != PARSE_OK || nrec > max_records || st->seq_bytes > seq_capacity) return;
-    for (uint64_t i = ((uint64_t)blockIdx.x * PB + threadIdx.x) / G; i < nlines; i += (uint64_t)gridDim.x * (PB / G)) {
+    // FASTQ: only the second and fourth line of a record are copied, so the lane groups are dealt
+    // out over those (two per record); FASTA: over all lines
+    const uint64_t nwork = FASTQ ? 2 * ((nlines + 3) / 4) : nlines;
+    for (uint64_t w = ((uint64_t)blockIdx.x * PB + threadIdx.x) / G; w < nwork; w += (uint64_t)gridDim.x * (PB / G)) {
+        const uint64_t i = FASTQ ? 4 * (w >> 1) + 1 + 2 * (w & 1) : w;
+        if (i >= nlines) continue;
         uint8_t* dst_plane;
         uint64_t dst;
         if (FASTQ) {
             const uint32_t role = (uint32_t)(i & 3);
-            if ((role != 1 && role != 3) || (i >> 2) >= nrec) continue;
+            if ((i >> 2) >= nrec) continue;
             dst_plane = role == 1 ? seq : qual;
             dst = line_dst[role == 1 ? i : i - 2];
         } else {
@@ -501,10 +506,13 @@ __global__ __launch_bounds__(PB) void k_parse_copy(const ParseState* st, uint64_
         const uint8_t* src = text + line_start[i];
         uint8_t* out = dst_plane + dst;
         for (uint32_t p = j * 16; p < len; p += G * 16) {
+            uint4 v;
             if (p + 16 <= len) {
-                uint4 v;
                 __builtin_memcpy(&v, src + p, 16);
                 __builtin_memcpy(out + p, &v, 16);
+            } else if (len >= 16) {                      // the last 16 bytes again: same values, no byte loop
+                __builtin_memcpy(&v, src + len - 16, 16);
+                __builtin_memcpy(out + len - 16, &v, 16);
             } else {
                 for (uint32_t k = p; k < len; k++) out[k] = src[k];
             }
