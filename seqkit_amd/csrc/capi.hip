@@ -55,6 +55,8 @@ struct skh_ctx {
     hipStream_t stream = nullptr;
     uint32_t* d_flags = nullptr;           // ring of "long records seen" words
     std::atomic<uint32_t> flag_next{0};
+    uint64_t* d_stat_slots = nullptr;      // ring of scratch areas of the stats kernel (partial gap sums)
+    std::atomic<uint32_t> slots_next{0};
     uint32_t max_grid = 0;
     uint32_t n_cu = 256;
     int force_logG = -1;
@@ -167,6 +169,7 @@ int skh_init(int device, skh_ctx** out)
     e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->d_flags), N_FLAGS * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemset(c->d_flags, 0, N_FLAGS * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->d_stat_slots), N_FLAGS * skh::STATS_SLOT_WORDS * 8);
     if (e != hipSuccess) {
         skh_destroy(c);
         return hip_fail(e, "skh_init");
@@ -181,6 +184,7 @@ void skh_destroy(skh_ctx* c)
     (void)hipSetDevice(c->device);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     if (c->d_flags) (void)hipFree(c->d_flags);
+    if (c->d_stat_slots) (void)hipFree(c->d_stat_slots);
     delete c;
 }
 
@@ -381,8 +385,9 @@ int skh_stats_dev(skh_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_offsets,
     memcpy(t.v, is_gap, 256);
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    uint64_t* slots = ctx->d_stat_slots + (uint64_t)(ctx->slots_next.fetch_add(1) % N_FLAGS) * skh::STATS_SLOT_WORDS;
     HIP_TRY(skh::launch_stats(cfg_for(ctx, nrec, total_bytes), d_seq, d_offsets, nrec, total_bytes, t,
-                              reinterpret_cast<skh::StatsPartial*>(d_out), st));
+                              reinterpret_cast<skh::StatsPartial*>(d_out), slots, st));
     return SKH_OK;
 }
 

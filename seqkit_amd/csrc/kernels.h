@@ -39,8 +39,10 @@ hipError_t launch_count(const LaunchCfg& cfg, const uint8_t* seq, const uint64_t
 // present: nrec x 8 words, bit (b & 31) of word (b >> 5) set when byte value b occurs in the record
 hipError_t launch_letters(const LaunchCfg& cfg, const uint8_t* seq, const uint64_t* offs, uint64_t nrec, uint64_t total,
                           uint32_t* present, uint32_t* n_long, hipStream_t st);
+// slots: STATS_SLOT_WORDS words of device scratch for this launch (partial gap sums)
+constexpr uint32_t STATS_SLOT_WORDS = 512;
 hipError_t launch_stats(const LaunchCfg& cfg, const uint8_t* seq, const uint64_t* offs, uint64_t nrec,
-                        uint64_t total, const Table256& is_gap, StatsPartial* out, hipStream_t st);
+                        uint64_t total, const Table256& is_gap, StatsPartial* out, uint64_t* slots, hipStream_t st);
 
 struct ValidateResult { uint64_t record, offset; uint32_t letter, found; };   // mirrors skh_validate_result
 hipError_t launch_validate(const LaunchCfg& cfg, const uint8_t* seq, const uint64_t* offs, uint64_t nrec,

@@ -1227,11 +1227,14 @@ __global__ void k_stats_init(StatsPartial* out, uint64_t nrec, uint64_t total)
 // address order: workgroup b reads `steps` runs of STATS_U * SKH_BLOCK consecutive chunks (the loads of a run
 // issued before its first table lookup) and its share `rpb` of the records, then reduces once.
 constexpr int STATS_U = 4;
+constexpr uint32_t STATS_SLOTS = 512;      // = skh::STATS_SLOT_WORDS: partial gap sums of a launch
+static_assert(STATS_SLOTS == STATS_SLOT_WORDS, "slot count");
 
 __global__ __launch_bounds__(SKH_BLOCK) void k_stats(const uint8_t* __restrict__ seq,
                                                      const uint64_t* __restrict__ offs, uint64_t nrec,
                                                      uint64_t total, uint64_t rpb, uint32_t steps, Table256 is_gap,
-                                                     StatsPartial* __restrict__ out)
+                                                     StatsPartial* __restrict__ out,
+                                                     unsigned long long* __restrict__ slots)
 {
     __shared__ uint8_t s_gap[256];
     __shared__ unsigned long long s_sum[SKH_BLOCK / 64];
@@ -1289,11 +1292,28 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_stats(const uint8_t* __restrict__
         }
         // the grid is large: only a workgroup that improves on the totals so far touches them
         // (atomics on one address are served one after the other)
-        if (gaps) atomicAdd(reinterpret_cast<unsigned long long*>(&out->gap_sum), gaps);
+        // (the gap count goes to one of STATS_SLOTS words, summed by k_stats_finish: with gaps in the
+        // data every workgroup has something to add, and one word would take them one by one)
+        if (gaps) atomicAdd(&slots[blockIdx.x & (STATS_SLOTS - 1)], gaps);
         if (lmin < *reinterpret_cast<volatile long long*>(&out->len_min))
             atomicMin(reinterpret_cast<long long*>(&out->len_min), lmin);
         if (lmax > *reinterpret_cast<volatile long long*>(&out->len_max))
             atomicMax(reinterpret_cast<long long*>(&out->len_max), lmax);
+    }
+}
+
+__global__ __launch_bounds__(STATS_SLOTS) void k_stats_finish(const unsigned long long* __restrict__ slots,
+                                                              StatsPartial* __restrict__ out)
+{
+    __shared__ unsigned long long s_w[STATS_SLOTS / 64];
+    unsigned long long v = slots[threadIdx.x];
+    for (uint32_t m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (uint32_t w = 0; w < STATS_SLOTS / 64; w++) t += s_w[w];
+        out->gap_sum = (int64_t)t;
     }
 }
 
@@ -1510,8 +1530,10 @@ hipError_t launch_letters(const LaunchCfg& cfg, const uint8_t* seq, const uint64
 }
 
 hipError_t launch_stats(const LaunchCfg& cfg, const uint8_t* seq, const uint64_t* offs, uint64_t nrec,
-                        uint64_t total, const Table256& is_gap, StatsPartial* out, hipStream_t st)
+                        uint64_t total, const Table256& is_gap, StatsPartial* out, uint64_t* slots, hipStream_t st)
 {
+    hipError_t e0 = hipMemsetAsync(slots, 0, STATS_SLOTS * 8, st);
+    if (e0 != hipSuccess) return e0;
     hipLaunchKernelGGL(k_stats_init, dim3(1), dim3(1), 0, st, out, nrec, total);
     const uint32_t steps = cfg.stats_steps > 0 ? (uint32_t)cfg.stats_steps : 4u;
     const uint64_t per_block = (uint64_t)STATS_U * SKH_BLOCK * steps;
@@ -1521,7 +1543,9 @@ hipError_t launch_stats(const LaunchCfg& cfg, const uint8_t* seq, const uint64_t
     if (g < 1) g = 1;
     if (g > 0x7fffffffull) return hipErrorInvalidValue;
     const uint64_t rpb = (nrec + g - 1) / g;
-    hipLaunchKernelGGL(k_stats, dim3((uint32_t)g), dim3(SKH_BLOCK), 0, st, seq, offs, nrec, total, rpb, steps, is_gap, out);
+    hipLaunchKernelGGL(k_stats, dim3((uint32_t)g), dim3(SKH_BLOCK), 0, st, seq, offs, nrec, total, rpb, steps, is_gap, out,
+                       reinterpret_cast<unsigned long long*>(slots));
+    hipLaunchKernelGGL(k_stats_finish, dim3(1), dim3(STATS_SLOTS), 0, st, reinterpret_cast<const unsigned long long*>(slots), out);
     return hipGetLastError();
 }
 
