@@ -93,8 +93,12 @@ skh::LaunchCfg cfg_for(const skh_ctx* ctx, uint64_t nrec, uint64_t total)
     c.max_grid = ctx->max_grid;
     c.n_cu = ctx->n_cu;
     // span kernel (lanes own consecutive output chunks) for read sets dominated by records of
-    // many KiB (nanopore-like); lane-group / staged kernels otherwise.  SKH_SPAN_U overrides.
-    c.span_u = ctx->span_u >= 0 ? ctx->span_u : ((nrec && total / nrec >= 8192) ? 4 : 0);
+    // many KiB (nanopore-like: 54 % of HBM peak against 42 % for lane groups + windows); lane-group /
+    // staged kernels for short reads, and for records of megabytes the window kernel, whose windows
+    // then lie inside one record almost always (24 chromosomes: 63 % against 53 % for the span kernel).
+    // SKH_SPAN_U overrides.
+    const uint64_t mean_len = nrec ? total / nrec : 0;
+    c.span_u = ctx->span_u >= 0 ? ctx->span_u : ((mean_len >= 8192 && mean_len < (1ull << 20)) ? 4 : 0);
     c.fuse_fastq = ctx->fuse_fastq;
     c.staged = ctx->staged;
     c.staged_steps = ctx->staged_steps;
