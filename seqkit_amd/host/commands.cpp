@@ -265,6 +265,7 @@ class BlockPipe {
         bool fastq = false;              // written by the parser before the first block is handed on
         uint64_t chunk = 0;              // most the reader puts into a block at once (what an ordinary block takes)
         uint64_t block_bytes = 0;        // size of an ordinary block
+        uint64_t largest_cap = 0;        // largest enlarged block so far (parser thread only)
         void fail(const std::string& m) { std::lock_guard<std::mutex> l(err_mu); if (err.empty()) err = m; }
         std::string error() { std::lock_guard<std::mutex> l(err_mu); return err; }
     };
@@ -392,8 +393,12 @@ private:
     // `b` replaced in the round by a new block of at least `cap` bytes (contents are not copied)
     static Block* replace_block(State& s, Block* b, uint64_t cap)
     {
+        // a file that made one block grow will make the others grow too: they go to the largest size
+        // seen so far at once instead of doubling their way up (every step pins fresh memory)
+        if (cap < s.largest_cap) cap = s.largest_cap;
         Block* nb = new_block(s, cap, true);
         if (!nb) return nullptr;
+        if (nb->cap > s.largest_cap) s.largest_cap = nb->cap;
         for (auto& x : s.all) if (x == b) x = nb;
         return nb;
     }
