@@ -165,3 +165,30 @@ def test_parse_at_rejects_text_beyond_the_buffer(lib, ctx):
         assert lib.skh_text_parse_at(ctx, t, cap + 1, 0, 1, 1, C.byref(res)) == -5
     finally:
         lib.skh_text_free(t)
+
+
+def test_format_submit_then_wait_equals_the_blocking_call(lib, ctx, plain_fixtures):
+    # two blocks: the first one's output is on its way while the second one is parsed and formatted
+    from seqkit_amd.capi import SeqFormat
+    text_a = fixture_text(plain_fixtures, "Illimina1.8.fq")
+    text_b = fixture_text(plain_fixtures, "reads_1.fq")
+    a, b = Block(lib, ctx, len(text_a) + 64), Block(lib, ctx, len(text_b) + 64)
+    try:
+        f = SeqFormat(min_len=-1, max_len=-1, line_width=0, print_name=1, print_seq=1, print_qual=1, plus_line=1,
+                      only_id=0, mark=b"@", empty_as_fasta=0)
+        assert a.parse_at(text_a, 0, 2).status == 0
+        want_a = a.format_seq(qual=1, mark=b"@")
+        lib.check(lib.skh_text_format_seq_submit(ctx, a.t, C.byref(f)))
+        assert b.parse_at(text_b, 0, 2).status == 0
+        want_b = b.format_seq(qual=1, mark=b"@")
+        lib.check(lib.skh_text_format_seq_submit(ctx, b.t, C.byref(f)))
+        out, n = C.c_void_p(), C.c_uint64()
+        lib.check(lib.skh_text_output_wait(ctx, a.t, C.byref(out), C.byref(n)))
+        assert C.string_at(out, n.value) == want_a
+        lib.check(lib.skh_text_output_wait(ctx, b.t, C.byref(out), C.byref(n)))
+        assert C.string_at(out, n.value) == want_b
+        lib.check(lib.skh_text_output_wait(ctx, b.t, C.byref(out), C.byref(n)))      # nothing pending any more
+        assert n.value == 0
+    finally:
+        a.close()
+        b.close()
