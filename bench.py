@@ -167,8 +167,9 @@ def end_to_end(nrec, L, seq, qual):
                "unit": "Gbases/s", "wall_s": round(best, 4), "input_bytes": nbytes,
                "note": "best of 3, page cache warm, process start to exit, host<->device copies included"}
         if cpu:
-            out["cpu"] = {"command": "oracle seq -r -p (plain C restatement, 1 thread) on the first %d records" % n_small,
-                          "value": round(n_small * L / cpu / 1e9, 3), "unit": "Gbases/s", "wall_s": round(cpu, 4)}
+            out["cpu_baseline"] = {"command": "oracle seq -r -p (plain C restatement, 1 thread) on the first %d records" % n_small,
+                                   "value": round(n_small * L / cpu / 1e9, 3), "unit": "Gbases/s", "wall_s": round(cpu, 4),
+                                   "cores": 1, "kind": "port"}
         return out
     finally:
         shutil.rmtree(d, ignore_errors=True)
