@@ -1,6 +1,7 @@
 #!/bin/bash
 # End-to-end (text in -> text out) rates of the seqkit-hip driver and of the CPU restatement on
-# the same synthetic files, page cache warm, output to /dev/null.  GPU box only.
+# the same synthetic files, page cache warm, output to /dev/null; then both outputs once more through
+# md5sum (they must be equal).  GPU box only.
 set -e
 mkdir -p gpurun_out
 NREC=${NREC:-4000000}
@@ -19,6 +20,7 @@ for cmd in "seq -r -p" "fx2tab -n -l -g -B AGCT" "stats"; do
   for f in $FQ $FA; do
     echo "gpu driver  $cmd $(basename $f): $(t timeout -k 10 300 ./seqkit_amd/seqkit-hip $cmd $f)"
     echo "cpu oracle  $cmd $(basename $f): $(t timeout -k 10 300 ./oracle/seqkit_oracle $cmd $f)"
+    echo "md5 gpu / cpu: $(./seqkit_amd/seqkit-hip $cmd $f | md5sum | cut -c1-32) $(./oracle/seqkit_oracle $cmd $f | md5sum | cut -c1-32)"
   done
 done
 } | tee gpurun_out/e2e.log
