@@ -1,9 +1,13 @@
-// commands.cpp -- `seq`, `fx2tab`, `stats` on top of the C ABI.
+// commands.cpp -- `seq`, `fx2tab`, `stats`, `subseq`, `convert` on top of the C ABI.
 //
 // Each command mirrors the record loop of its Go counterpart (seqkit/cmd/seq.go:114-280,
-// fx2tab.go:95-150, stat.go:86-161) but works a batch at a time: while the GPU transforms or
-// counts batch i, the host formats batch i-1 and parses batch i+1 (two pinned batches,
-// skh_*_submit / skh_batch_wait).
+// fx2tab.go:95-150, stat.go:86-161, subseq.go, convert.go) but works a block of file text at a
+// time: the text is parsed, transformed or counted, and formatted on the GPU (skh_text_*), with
+// a reader thread, a parser thread and the command itself working on different blocks at once
+// (BlockPipe).  With --host-parse the host scans and prints the records instead and only the
+// per-record work goes to the GPU, a batch at a time: while the GPU transforms or counts batch i,
+// the host formats batch i-1 and parses batch i+1 (two pinned batches, skh_*_submit /
+// skh_batch_wait).
 #include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
