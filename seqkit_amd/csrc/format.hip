@@ -240,7 +240,7 @@ __global__ __launch_bounds__(FB) void k_fmt_write_long(const FormatSeqArgs a, co
         const uint64_t t0 = tile * SKH_TILE;
         const uint64_t t1 = t0 + SKH_TILE < plane ? t0 + SKH_TILE : plane;
         const uint64_t r_lo = find_record(a.offsets, a.nrec, t0);
-        const uint64_t r_hi = find_record(a.offsets, a.nrec, t1 - 1);
+        const uint64_t r_hi = a.offsets[r_lo + 1] > t1 - 1 ? r_lo : find_record(a.offsets, a.nrec, t1 - 1);
 #pragma unroll 1
         for (int c = 0; c < 2; c++) {
             if (c == 1 && r_hi == r_lo) break;
@@ -408,7 +408,7 @@ __global__ __launch_bounds__(FB) void k_tab_write_long(const FormatTabArgs a, co
         const uint64_t t0 = tile * SKH_TILE;
         const uint64_t t1 = t0 + SKH_TILE < plane ? t0 + SKH_TILE : plane;
         const uint64_t r_lo = find_record(a.offsets, a.nrec, t0);
-        const uint64_t r_hi = find_record(a.offsets, a.nrec, t1 - 1);
+        const uint64_t r_hi = a.offsets[r_lo + 1] > t1 - 1 ? r_lo : find_record(a.offsets, a.nrec, t1 - 1);
 #pragma unroll 1
         for (int c = 0; c < 2; c++) {
             if (c == 1 && r_hi == r_lo) break;

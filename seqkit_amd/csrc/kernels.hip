@@ -650,7 +650,8 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_reverse_tiles(RevPlanes P, uint64
         const uint64_t t1 = t0 + SKH_TILE;                       // exclusive, may exceed total
         const uint64_t last = (t1 < total ? t1 : total) - 1;     // last real byte of the window
         const uint64_t r_lo = find_record(P.offs, nrec, t0);
-        const uint64_t r_hi = find_record(P.offs, nrec, last);
+        // (a record that reaches beyond the window is the last one too: no second search)
+        const uint64_t r_hi = P.offs[r_lo + 1] > last ? r_lo : find_record(P.offs, nrec, last);
 #pragma unroll 1
         for (int c = 0; c < 2; c++) {
             if (c == 1 && r_hi == r_lo) break;
@@ -1063,7 +1064,7 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_count_tiles(
         const uint64_t t1 = t0 + SKH_TILE;
         const uint64_t last = (t1 < total ? t1 : total) - 1;
         const uint64_t r_lo = find_record(offs, nrec, t0);
-        const uint64_t r_hi = find_record(offs, nrec, last);
+        const uint64_t r_hi = offs[r_lo + 1] > last ? r_lo : find_record(offs, nrec, last);
 #pragma unroll 1
         for (int c = 0; c < 2; c++) {
             if (c == 1 && r_hi == r_lo) break;
@@ -1177,7 +1178,7 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_letters_tiles(const uint8_t* __re
         const uint64_t t1 = t0 + SKH_TILE;
         const uint64_t last = (t1 < total ? t1 : total) - 1;
         const uint64_t r_lo = find_record(offs, nrec, t0);
-        const uint64_t r_hi = find_record(offs, nrec, last);
+        const uint64_t r_hi = offs[r_lo + 1] > last ? r_lo : find_record(offs, nrec, last);
 #pragma unroll 1
         for (int c = 0; c < 2; c++) {
             if (c == 1 && r_hi == r_lo) break;
