@@ -23,6 +23,7 @@
 #include <memory>
 #include <mutex>
 #include <thread>
+#include <type_traits>
 
 #include "host.h"
 
@@ -1644,10 +1645,12 @@ bool encodings_match(int a, int b, bool force)                                  
 
 }  // namespace
 
-// convert.go:42-275.  The source encoding is guessed from the first -n records of the input (the
-// first block is grown until it holds them), then every block's quality plane is checked and
-// looked up on the GPU and printed as FASTQ.  A file shorter than -n records is decided at its end,
-// as in the reference; unlike the reference, its records are not printed again with a later file.
+// convert.go:42-275.  The source encoding is guessed from the first -n records of the input, then
+// every block's quality plane is checked and looked up on the GPU and printed as FASTQ.  A file
+// that can be opened twice is opened once for the guess (a small block that is grown until it
+// holds the records) and then goes through the block pipeline; standard input is read once, its
+// first block grown until it holds the records.  A file shorter than -n records is decided at its
+// end, as in the reference; unlike the reference, its records are not printed again with a later file.
 int cmd_convert(const GlobalOpts& g, const ConvertOpts& o, const std::vector<std::string>& files)
 {
     if (g.host_parse) return fatal("convert has no --host-parse mode");
@@ -1666,46 +1669,70 @@ int cmd_convert(const GlobalOpts& g, const ConvertOpts& o, const std::vector<std
     if (!out.ok()) return fatal("open " + g.out_file + ": cannot create");
     std::vector<uint64_t> offs;
     std::vector<uint8_t> qual;
-    for (const std::string& file : files) {
-        TextBlocks tb(ctx.c, file, g.text_block_bytes);
-        if (!tb.ok()) return fatal(tb.error());
+
+    // convert.go:177-238 on the leading records of a parsed block
+    auto needs_larger_block = [&](uint64_t nrec, bool at_eof) { return nrec <= (uint64_t)(o.nrecords - n) && !at_eof; };
+    auto guess_from = [&](skh_text* t, uint64_t nrec) -> int {
+        const uint64_t look = std::min<uint64_t>(nrec, (uint64_t)(o.nrecords - n));
+        offs.resize(look + 1);
+        if (skh_text_offsets(ctx.c, t, 0, look + 1, offs.data()) != SKH_OK) return fatal(skh_last_error());
+        qual.resize(offs[look] ? offs[look] : 1);
+        if (offs[look] && skh_text_quality(ctx.c, t, 0, offs[look], qual.data()) != SKH_OK) return fatal(skh_last_error());
+        for (uint64_t r = 0; r < look; r++) {
+            const unsigned set = guess_quality_encoding(qual.data() + offs[r], offs[r + 1] - offs[r], o.n_most_common);
+            for (int e = 0; e < 6; e++) if (set & (1u << e)) marks[e]++;
+        }
+        n += (int)look;
+        std::string err;
+        from = decide_encoding(marks, n, o.nrecords, o.illumina15_frac, err);
+        if (from == 0) return fatal(err);
+        fprintf(stderr, "[INFO] converting %s -> %s\n", quality_name(from), quality_name(o.to));
+        if (skh_quality_table(from, o.to, o.force, lut, valid, &identity) != SKH_OK) return fatal(skh_last_error());
+        if (n >= o.nrecords) guessing = false;                             // else: decided at the end of a short file
+        return 0;
+    };
+
+    // the blocks of one file, through either reader
+    auto convert_blocks = [&](auto& tb) -> int {
+        constexpr bool one_pass = std::is_same<typename std::decay<decltype(tb)>::type, TextBlocks>::value;
         bool once = true;
         std::string pending_error;
         skh_parse_result res;
-        while (pending_error.empty() && tb.next(res)) {
+        void* held = nullptr;                                               // pipeline: the block whose output is on its way
+        auto flush_held = [&]() -> int {
+            if constexpr (!one_pass) {
+                if (!held) return 0;
+                const uint8_t* text = nullptr;
+                uint64_t nbytes = 0;
+                {
+                    PhaseTimer pt(3);
+                    if (skh_text_output_wait(ctx.c, BlockPipe::text_of(held), &text, &nbytes) != SKH_OK) return fatal(skh_last_error());
+                }
+                { PhaseTimer pt(4); out.write(text, nbytes); }
+                tb.release(held);
+                held = nullptr;
+            }
+            return 0;
+        };
+        auto one_block = [&](bool& stop) -> int {
             skh_text* t = tb.block();
-            if (res.nrec == 0) { tb.advance(res); continue; }
+            if (res.nrec == 0) { tb.advance(res); return 0; }
             if (!tb.is_fastq()) return fatal("this command only works for FASTQ format");
-            if (guessing) {
-                const uint64_t want = (uint64_t)(o.nrecords - n);           // records still to look at
-                if (res.nrec <= want && !tb.at_eof()) {
-                    // the decision needs more records than this block holds: a larger block
-                    // (records seen so far in it are looked at again)
-                    if (!tb.grow()) return fatal(tb.error());
-                    continue;
+            if constexpr (one_pass) {
+                if (guessing) {
+                    if (needs_larger_block(res.nrec, tb.at_eof())) {
+                        // records seen so far are looked at again in the larger block
+                        if (!tb.grow()) return fatal(tb.error());
+                        return 0;
+                    }
+                    if (int rc = guess_from(t, res.nrec)) return rc;
                 }
-                const uint64_t look = std::min<uint64_t>(res.nrec, want);
-                offs.resize(look + 1);
-                if (skh_text_offsets(ctx.c, t, 0, look + 1, offs.data()) != SKH_OK) return fatal(skh_last_error());
-                qual.resize(offs[look] ? offs[look] : 1);
-                if (offs[look] && skh_text_quality(ctx.c, t, 0, offs[look], qual.data()) != SKH_OK) return fatal(skh_last_error());
-                for (uint64_t r = 0; r < look; r++) {
-                    const unsigned set = guess_quality_encoding(qual.data() + offs[r], offs[r + 1] - offs[r], o.n_most_common);
-                    for (int e = 0; e < 6; e++) if (set & (1u << e)) marks[e]++;
-                }
-                n += (int)look;
-                std::string err;
-                from = decide_encoding(marks, n, o.nrecords, o.illumina15_frac, err);
-                if (from == 0) return fatal(err);
-                fprintf(stderr, "[INFO] converting %s -> %s\n", quality_name(from), quality_name(o.to));
-                if (skh_quality_table(from, o.to, o.force, lut, valid, &identity) != SKH_OK) return fatal(skh_last_error());
-                if (n >= o.nrecords) guessing = false;                     // else: decided at the end of a short file
             }
             if (once && encodings_match(from, o.to, o.force)) {
                 once = false;
                 fprintf(stderr, "[WARN] source and target quality encoding match.\n");
             }
-            if (o.dry_run) break;
+            if (o.dry_run) { stop = true; return 0; }
             if (!identity) {
                 skh_validate_result vr;
                 if (skh_text_validate_quality(ctx.c, t, valid, &vr) != SKH_OK) return fatal(skh_last_error());
@@ -1713,7 +1740,7 @@ int cmd_convert(const GlobalOpts& g, const ConvertOpts& o, const std::vector<std
                     pending_error = std::string("seq: invalid ") + (from == SKH_Q_SOLEXA ? "Solexa" : "Phred") + " quality";
                     if (skh_text_truncate(ctx.c, t, vr.record) != SKH_OK) return fatal(skh_last_error());
                     res.nrec = vr.record;
-                    if (res.nrec == 0) break;
+                    if (res.nrec == 0) { stop = true; return 0; }
                 }
                 PhaseTimer pt(2);
                 if (skh_text_map_quality(ctx.c, t, lut) != SKH_OK) return fatal(skh_last_error());
@@ -1724,17 +1751,64 @@ int cmd_convert(const GlobalOpts& g, const ConvertOpts& o, const std::vector<std
             f.line_width = 0;                                               // convert.go:171-172
             f.print_name = 1; f.print_seq = 1; f.print_qual = 1; f.plus_line = 1; f.mark = '@';
             f.empty_as_fasta = 1;                                           // Record.FormatToWriter: layout per record
-            const uint8_t* text = nullptr;
-            uint64_t nbytes = 0;
-            {
-                PhaseTimer pt(3);
-                if (skh_text_format_seq(ctx.c, t, &f, &text, &nbytes) != SKH_OK) return fatal(skh_last_error());
+            if constexpr (one_pass) {
+                const uint8_t* text = nullptr;
+                uint64_t nbytes = 0;
+                {
+                    PhaseTimer pt(3);
+                    if (skh_text_format_seq(ctx.c, t, &f, &text, &nbytes) != SKH_OK) return fatal(skh_last_error());
+                }
+                { PhaseTimer pt(4); out.write(text, nbytes); }
+                if (pending_error.empty()) tb.advance(res);
+            } else {
+                // the download of this block's output runs beside the next block's kernels
+                {
+                    PhaseTimer pt(3);
+                    if (skh_text_format_seq_submit(ctx.c, t, &f) != SKH_OK) return fatal(skh_last_error());
+                }
+                if (int rc = flush_held()) return rc;
+                held = tb.hold();
             }
-            { PhaseTimer pt(4); out.write(text, nbytes); }
-            if (pending_error.empty()) tb.advance(res);
+            return 0;
+        };
+        bool stop = false;
+        while (!stop && pending_error.empty() && tb.next(res)) {
+            if (int rc = one_block(stop)) { flush_held(); return rc; }
         }
+        if (int rc = flush_held()) return rc;
         if (!pending_error.empty()) { out.flush(); return fatal(pending_error); }
         if (!tb.error().empty()) return fatal(tb.error());
+        return 0;
+    };
+
+    for (const std::string& file : files) {
+        struct stat st;
+        const bool opens_twice = file != "-" && stat(file.c_str(), &st) == 0 && S_ISREG(st.st_mode);
+        if (!opens_twice) {
+            TextBlocks tb(ctx.c, file, g.text_block_bytes);
+            if (!tb.ok()) return fatal(tb.error());
+            if (int rc = convert_blocks(tb)) return rc;
+            continue;
+        }
+        if (guessing) {
+            TextBlocks tb(ctx.c, file, std::min<uint64_t>(g.text_block_bytes, 4u << 20));
+            if (!tb.ok()) return fatal(tb.error());
+            skh_parse_result res;
+            while (tb.next(res)) {
+                if (res.nrec == 0) { tb.advance(res); continue; }
+                if (!tb.is_fastq()) return fatal("this command only works for FASTQ format");
+                if (needs_larger_block(res.nrec, tb.at_eof())) {
+                    if (!tb.grow()) return fatal(tb.error());
+                    continue;
+                }
+                if (int rc = guess_from(tb.block(), res.nrec)) return rc;
+                break;
+            }
+            if (!tb.error().empty()) return fatal(tb.error());
+        }
+        BlockPipe tb(ctx.c, file, g.text_block_bytes);
+        if (!tb.ok()) return fatal(tb.error());
+        if (int rc = convert_blocks(tb)) return rc;
     }
     return 0;
 }

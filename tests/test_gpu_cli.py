@@ -421,3 +421,46 @@ def test_convert_rejects_fasta(cli, oracle_cli):
     got = run_cli(cli, ["convert", "contigs.fa"])
     assert got[0] == want[0] == 255 and got[1] == want[1] == b"" and got[2] == want[2]
     assert run_cli(cli, ["convert", "--to", "phred", "reads_1.fq.gz"])[0] == 255
+
+
+def test_convert_files_through_the_block_pipeline(cli, oracle_cli, tmp_path):
+    # regular files go through the pipelined reader (the guess is made on a first, small read of
+    # the file), standard input through the one-pass reader: same bytes, same messages, also with
+    # an invalid score in the middle of a file, a file shorter than -n, and blocks much smaller
+    # than the files
+    import random
+    rnd = random.Random(77)
+
+    def fastq(nrec, lo, hi, bad_at=None):
+        recs = []
+        for i in range(nrec):
+            n = rnd.randint(0, 160)
+            q = "".join(chr(rnd.randint(lo, hi)) for _ in range(n))
+            if i == bad_at:
+                q, n = "!!!" + q, n + 3
+            recs.append("@r%d x\n%s\n+\n%s\n" % (i, "".join(rnd.choice("ACGTN") for _ in range(n)), q))
+        return "".join(recs)
+
+    short = tmp_path / "short.fq"
+    short.write_text(fastq(40, 33, 73))
+    long_ = tmp_path / "long.fq"
+    long_.write_text(fastq(5000, 33, 73))
+    bad = tmp_path / "bad.fq"
+    bad.write_text(fastq(3000, 64, 104, bad_at=2100))
+    to13 = ["convert", "--to", "Illumina-1.3+"]
+    for args in (["convert", str(long_)],
+                 to13 + [str(long_)],
+                 to13 + [str(short)],
+                 to13 + [str(long_), str(short)],
+                 to13 + ["-n", "4000", str(long_), str(short)],
+                 ["convert", "--from", "Illumina-1.3+", str(bad), str(long_)],
+                 to13 + ["-n", "50", str(long_), str(bad)],
+                 to13 + ["-d", str(short), str(long_)]):
+        want = run_cli(oracle_cli, args)
+        for extra in ([], ["--batch-bytes", "16384"]):
+            got = run_cli(cli, args + extra)
+            assert got == want, (args, extra)
+    text = long_.read_text()
+    want = run_cli(oracle_cli, ["convert", "-n", "4000"], stdin=text)
+    for extra in ([], ["--batch-bytes", "16384"]):
+        assert run_cli(cli, ["convert", "-n", "4000"] + extra, stdin=text) == want
