@@ -1672,7 +1672,10 @@ int cmd_convert(const GlobalOpts& g, const ConvertOpts& o, const std::vector<std
 
     // convert.go:177-238 on the leading records of a parsed block
     auto needs_larger_block = [&](uint64_t nrec, bool at_eof) { return nrec <= (uint64_t)(o.nrecords - n) && !at_eof; };
-    auto guess_from = [&](skh_text* t, uint64_t nrec) -> int {
+    // `skip`: the input ended with exactly -n records looked at -- the reference decides on the record
+    // after those (convert.go:184) or at the end of a shorter input (convert.go:99), so such a file
+    // is neither decided nor printed
+    auto guess_from = [&](skh_text* t, uint64_t nrec, bool at_eof, bool& skip) -> int {
         const uint64_t look = std::min<uint64_t>(nrec, (uint64_t)(o.nrecords - n));
         offs.resize(look + 1);
         if (skh_text_offsets(ctx.c, t, 0, look + 1, offs.data()) != SKH_OK) return fatal(skh_last_error());
@@ -1683,6 +1686,8 @@ int cmd_convert(const GlobalOpts& g, const ConvertOpts& o, const std::vector<std
             for (int e = 0; e < 6; e++) if (set & (1u << e)) marks[e]++;
         }
         n += (int)look;
+        skip = at_eof && look == nrec && n == o.nrecords;
+        if (skip) return 0;
         std::string err;
         from = decide_encoding(marks, n, o.nrecords, o.illumina15_frac, err);
         if (from == 0) return fatal(err);
@@ -1725,7 +1730,9 @@ int cmd_convert(const GlobalOpts& g, const ConvertOpts& o, const std::vector<std
                         if (!tb.grow()) return fatal(tb.error());
                         return 0;
                     }
-                    if (int rc = guess_from(t, res.nrec)) return rc;
+                    bool skip = false;
+                    if (int rc = guess_from(t, res.nrec, tb.at_eof(), skip)) return rc;
+                    if (skip) { stop = true; return 0; }
                 }
             }
             if (once && encodings_match(from, o.to, o.force)) {
@@ -1790,6 +1797,7 @@ int cmd_convert(const GlobalOpts& g, const ConvertOpts& o, const std::vector<std
             if (int rc = convert_blocks(tb)) return rc;
             continue;
         }
+        bool skip = false;
         if (guessing) {
             TextBlocks tb(ctx.c, file, std::min<uint64_t>(g.text_block_bytes, 4u << 20));
             if (!tb.ok()) return fatal(tb.error());
@@ -1801,11 +1809,12 @@ int cmd_convert(const GlobalOpts& g, const ConvertOpts& o, const std::vector<std
                     if (!tb.grow()) return fatal(tb.error());
                     continue;
                 }
-                if (int rc = guess_from(tb.block(), res.nrec)) return rc;
+                if (int rc = guess_from(tb.block(), res.nrec, tb.at_eof(), skip)) return rc;
                 break;
             }
             if (!tb.error().empty()) return fatal(tb.error());
         }
+        if (skip) continue;
         BlockPipe tb(ctx.c, file, g.text_block_bytes);
         if (!tb.ok()) return fatal(tb.error());
         if (int rc = convert_blocks(tb)) return rc;

@@ -455,6 +455,9 @@ def test_convert_files_through_the_block_pipeline(cli, oracle_cli, tmp_path):
                  to13 + ["-n", "4000", str(long_), str(short)],
                  ["convert", "--from", "Illumina-1.3+", str(bad), str(long_)],
                  to13 + ["-n", "50", str(long_), str(bad)],
+                 to13 + ["-n", "40", str(short)],             # exactly -n records: the reference prints nothing
+                 to13 + ["-n", "39", str(short)],
+                 to13 + ["-n", "41", str(short)],
                  to13 + ["-d", str(short), str(long_)]):
         want = run_cli(oracle_cli, args)
         for extra in ([], ["--batch-bytes", "16384"]):
@@ -464,3 +467,6 @@ def test_convert_files_through_the_block_pipeline(cli, oracle_cli, tmp_path):
     want = run_cli(oracle_cli, ["convert", "-n", "4000"], stdin=text)
     for extra in ([], ["--batch-bytes", "16384"]):
         assert run_cli(cli, ["convert", "-n", "4000"] + extra, stdin=text) == want
+    text = short.read_text()
+    for n in ("39", "40", "41"):
+        assert run_cli(cli, to13 + ["-n", n], stdin=text) == run_cli(oracle_cli, to13 + ["-n", n], stdin=text)
