@@ -101,7 +101,11 @@ skh::LaunchCfg cfg_for(const skh_ctx* ctx, uint64_t nrec, uint64_t total)
     c.span_u = ctx->span_u >= 0 ? ctx->span_u : ((mean_len >= 8192 && mean_len < (1ull << 20)) ? 4 : 0);
     c.fuse_fastq = ctx->fuse_fastq;
     c.staged = ctx->staged;
-    c.staged_steps = ctx->staged_steps;
+    // staged reverse kernel, steps per wavefront (SKH_STAGED_STEPS overrides).  Measured on batches of
+    // 5-10 M records: 150-base reads fastest with 2; 250-base reads 58 -> 63 % of HBM peak with 3;
+    // reads of about 100 bases and ragged 30-151-base reads gain 4-5 points with 6, where fewer of
+    // a lane group's chunk slots hold data and a wavefront has less in flight per step.
+    c.staged_steps = ctx->staged_steps ? ctx->staged_steps : mean_len < 128 ? 6 : (mean_len >= 192 && mean_len < 512) ? 3 : 2;
     c.count_steps = ctx->count_steps;
     c.stats_steps = ctx->stats_steps;
     if (ctx->force_logG >= 0) {
