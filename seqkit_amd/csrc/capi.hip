@@ -8,6 +8,8 @@
 #include <math.h>
 
 #include <atomic>
+#include <mutex>
+#include <unordered_map>
 #include <utility>
 #include <cstdio>
 #include <cstdlib>
@@ -40,7 +42,11 @@ int hip_fail(hipError_t e, const char* what)
         if (e_ != hipSuccess) return hip_fail(e_, #expr);       \
     } while (0)
 
-constexpr int N_FLAGS = 64;
+// Device scratch of a launch (its BatchHint, the partial sums of the stats kernel) is owned by the
+// STREAM the launch goes to: launches on one stream run one after the other, so they can share a
+// slot; launches on different streams get different slots however many are in flight.
+constexpr uint32_t N_SLOTS = 256;
+
 
 int env_int(const char* name, int dflt)
 {
@@ -53,15 +59,16 @@ int env_int(const char* name, int dflt)
 struct skh_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    uint32_t* d_flags = nullptr;           // ring of "long records seen" words
-    std::atomic<uint32_t> flag_next{0};
-    uint64_t* d_stat_slots = nullptr;      // ring of scratch areas of the stats kernel (partial gap sums)
-    std::atomic<uint32_t> slots_next{0};
+    skh::BatchHint* d_hints = nullptr;     // N_SLOTS launch hints, one per stream in use
+    uint64_t* d_stat_slots = nullptr;      // N_SLOTS scratch areas of the stats kernel (partial gap sums)
+    std::mutex slot_mu;
+    std::unordered_map<hipStream_t, uint32_t> slot_of;
     uint32_t max_grid = 0;
     uint32_t n_cu = 256;
     int force_logG = -1;
     int span_u = -1;         // -1 = chosen per call from the mean record length
     int fuse_fastq = 0;
+    int use_hint = 1;
     int staged = 1;
     uint32_t staged_steps = 0;
     uint32_t count_steps = 0;
@@ -108,30 +115,44 @@ skh::LaunchCfg cfg_for(const skh_ctx* ctx, uint64_t nrec, uint64_t total)
     c.staged_steps = ctx->staged_steps ? ctx->staged_steps : mean_len < 128 ? 6 : (mean_len >= 192 && mean_len < 512) ? 3 : 2;
     c.count_steps = ctx->count_steps;
     c.stats_steps = ctx->stats_steps;
+    c.use_hint = ctx->use_hint;
     if (ctx->force_logG >= 0) {
         c.logG = c.logG_count = ctx->force_logG > 6 ? 6 : ctx->force_logG;
+        c.use_hint = 0;
         return c;
     }
-    // about three 16-byte chunks per lane: 150-base reads -> 4 lanes per record
-    const uint64_t mean = nrec ? total / nrec : 0;
-    const uint64_t chunks = (mean + 15) / 16 + 1;
-    const uint64_t lanes = (chunks + 2) / 3;
-    int lg = 0;
-    while (lg < 6 && (1ull << lg) < lanes) lg++;
-    c.logG = lg;
-    // the counting kernel loops over a lane's chunks and has nothing to hold per chunk: four to five
-    // chunks per lane (measured: reads of ~100 bases 10-17 % faster with 2 lanes per record than with
-    // 4; 150 and 250 bases fastest with 4)
-    const uint64_t lanes_count = chunks <= 9 ? (chunks + 4) / 5 : (chunks + 5) / 5;
-    lg = 0;
-    while (lg < 6 && (1ull << lg) < lanes_count) lg++;
-    c.logG_count = lg;
+    c.logG = skh::lanes_log2_reverse(mean_len);
+    c.logG_count = skh::lanes_log2_count(mean_len);
     return c;
 }
 
-uint32_t* next_flag(skh_ctx* ctx)
+// The scratch slot of stream `st` on this context.  The library's own streams give their slot back
+// when they are destroyed (slot_release); with more than N_SLOTS caller streams alive at once the
+// device is drained (nothing in flight can then share a slot with a later launch) and the table
+// starts again.
+int slot_for(skh_ctx* ctx, hipStream_t st, uint32_t* slot)
 {
-    return ctx->d_flags + (ctx->flag_next.fetch_add(1) % N_FLAGS);
+    std::lock_guard<std::mutex> lock(ctx->slot_mu);
+    auto it = ctx->slot_of.find(st);
+    if (it == ctx->slot_of.end()) {
+        if (ctx->slot_of.size() >= N_SLOTS) {
+            HIP_TRY(hipDeviceSynchronize());
+            ctx->slot_of.clear();
+        }
+        bool used[N_SLOTS] = {false};
+        for (const auto& kv : ctx->slot_of) used[kv.second] = true;
+        uint32_t free_slot = 0;
+        while (used[free_slot]) free_slot++;
+        it = ctx->slot_of.emplace(st, free_slot).first;
+    }
+    *slot = it->second;
+    return SKH_OK;
+}
+
+void slot_release(skh_ctx* ctx, hipStream_t st)
+{
+    std::lock_guard<std::mutex> lock(ctx->slot_mu);
+    ctx->slot_of.erase(st);
 }
 
 int check_plane_args(const void* a, const void* offs, uint64_t nrec, uint64_t total)
@@ -170,14 +191,15 @@ int skh_init(int device, skh_ctx** out)
     c->force_logG = env_int("SKH_LOGG", -1);
     c->span_u = env_int("SKH_SPAN_U", -1);
     c->fuse_fastq = env_int("SKH_FUSE_FASTQ", 0);
+    c->use_hint = env_int("SKH_HINT", 1);
     c->staged = env_int("SKH_STAGED", 1);
     c->staged_steps = (uint32_t)env_int("SKH_STAGED_STEPS", 0);
     c->count_steps = (uint32_t)env_int("SKH_COUNT_STEPS", 0);
     c->stats_steps = (uint32_t)env_int("SKH_STATS_STEPS", 0);
     e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->d_flags), N_FLAGS * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMemset(c->d_flags, 0, N_FLAGS * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->d_stat_slots), N_FLAGS * skh::STATS_SLOT_WORDS * 8);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->d_hints), N_SLOTS * sizeof(skh::BatchHint));
+    if (e == hipSuccess) e = hipMemset(c->d_hints, 0, N_SLOTS * sizeof(skh::BatchHint));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->d_stat_slots), (size_t)N_SLOTS * skh::STATS_SLOT_WORDS * 8);
     if (e != hipSuccess) {
         skh_destroy(c);
         return hip_fail(e, "skh_init");
@@ -191,7 +213,7 @@ void skh_destroy(skh_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
-    if (c->d_flags) (void)hipFree(c->d_flags);
+    if (c->d_hints) (void)hipFree(c->d_hints);
     if (c->d_stat_slots) (void)hipFree(c->d_stat_slots);
     delete c;
 }
@@ -323,10 +345,10 @@ static int revcomp_impl(skh_ctx* ctx, const uint8_t* d_in, uint8_t* d_out, const
     if (lut) memcpy(t.v, lut, 256);
     const skh::LaunchCfg cfg = cfg_for(ctx, nrec, total);
     if (do_reverse) {
-        uint32_t* flag = next_flag(ctx);
-        HIP_TRY(hipMemsetAsync(flag, 0, sizeof(uint32_t), st));
+        uint32_t slot;
+        if ((rc = slot_for(ctx, st, &slot))) return rc;
         HIP_TRY(skh::launch_reverse(cfg, d_in, d_out, d_qin, d_qout, d_offs, nrec, total,
-                                    lut ? &t : nullptr, flag, st));
+                                    lut ? &t : nullptr, ctx->d_hints + slot, st));
     } else {
         if (lut) HIP_TRY(skh::launch_map_plane(cfg, d_in, d_out, total, t, st));
         else HIP_TRY(hipMemcpyAsync(d_out, d_in, total, hipMemcpyDeviceToDevice, st));
@@ -374,10 +396,10 @@ int skh_count_dev(skh_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_offsets,
     }
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
-    uint32_t* flag = next_flag(ctx);
-    HIP_TRY(hipMemsetAsync(flag, 0, sizeof(uint32_t), st));
+    uint32_t slot;
+    if ((rc = slot_for(ctx, st, &slot))) return rc;
     HIP_TRY(skh::launch_count(cfg_for(ctx, nrec, total_bytes), d_seq, d_offsets, nrec, total_bytes, t, nclass,
-                              neutral, d_counts, flag, st));
+                              neutral, d_counts, ctx->d_hints + slot, st));
     return SKH_OK;
 }
 
@@ -393,7 +415,9 @@ int skh_stats_dev(skh_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_offsets,
     memcpy(t.v, is_gap, 256);
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
-    uint64_t* slots = ctx->d_stat_slots + (uint64_t)(ctx->slots_next.fetch_add(1) % N_FLAGS) * skh::STATS_SLOT_WORDS;
+    uint32_t slot;
+    if ((rc = slot_for(ctx, st, &slot))) return rc;
+    uint64_t* slots = ctx->d_stat_slots + (uint64_t)slot * skh::STATS_SLOT_WORDS;
     HIP_TRY(skh::launch_stats(cfg_for(ctx, nrec, total_bytes), d_seq, d_offsets, nrec, total_bytes, t,
                               reinterpret_cast<skh::StatsPartial*>(d_out), slots, st));
     return SKH_OK;
@@ -409,9 +433,10 @@ int skh_letters_dev(skh_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_offset
     if (!d_present) return fail(SKH_EINVAL, "output pointer is NULL");
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
-    uint32_t* flag = next_flag(ctx);
-    HIP_TRY(hipMemsetAsync(flag, 0, sizeof(uint32_t), st));
-    HIP_TRY(skh::launch_letters(cfg_for(ctx, nrec, total_bytes), d_seq, d_offsets, nrec, total_bytes, d_present, flag, st));
+    uint32_t slot;
+    if ((rc = slot_for(ctx, st, &slot))) return rc;
+    HIP_TRY(skh::launch_letters(cfg_for(ctx, nrec, total_bytes), d_seq, d_offsets, nrec, total_bytes, d_present,
+                                ctx->d_hints + slot, st));
     return SKH_OK;
 }
 
@@ -439,10 +464,10 @@ int skh_remove_gaps_dev(skh_ctx* ctx, const uint8_t* d_seq, const uint8_t* d_qua
     for (int b = 0; b < 256; b++) t.v[b] = is_gap[b] ? 1 : 0;
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
-    uint32_t* flag = next_flag(ctx);
-    HIP_TRY(hipMemsetAsync(flag, 0, sizeof(uint32_t), st));
+    uint32_t slot;
+    if ((rc = slot_for(ctx, st, &slot))) return rc;
     HIP_TRY(skh::launch_remove_gaps(cfg_for(ctx, nrec, total_bytes), d_seq, d_qual, d_offsets, nrec, total_bytes, t, d_out_seq,
-                                    d_out_qual, d_out_offsets, d_workspace, d_out_bytes, flag, st));
+                                    d_out_qual, d_out_offsets, d_workspace, d_out_bytes, ctx->d_hints + slot, st));
     return SKH_OK;
 }
 
@@ -653,7 +678,7 @@ void skh_batch_free(skh_batch* b)
 {
     if (!b) return;
     (void)hipSetDevice(b->ctx->device);
-    if (b->stream) { (void)hipStreamSynchronize(b->stream); (void)hipStreamDestroy(b->stream); }
+    if (b->stream) { (void)hipStreamSynchronize(b->stream); slot_release(b->ctx, b->stream); (void)hipStreamDestroy(b->stream); }
     if (b->h_seq) (void)hipHostFree(b->h_seq);
     if (b->h_qual) (void)hipHostFree(b->h_qual);
     if (b->h_offs) (void)hipHostFree(b->h_offs);
@@ -958,7 +983,7 @@ void skh_text_free(skh_text* t)
 {
     if (!t) return;
     (void)hipSetDevice(t->ctx->device);
-    if (t->stream) { (void)hipStreamSynchronize(t->stream); (void)hipStreamDestroy(t->stream); }
+    if (t->stream) { (void)hipStreamSynchronize(t->stream); slot_release(t->ctx, t->stream); (void)hipStreamDestroy(t->stream); }
     text_free_lines(t);
     (void)hipFree(t->d_stage); (void)hipFree(t->d_goffs); (void)hipFree(t->d_gws); (void)hipFree(t->d_letters);
     (void)hipFree(t->d_text); (void)hipFree(t->d_seq); (void)hipFree(t->d_qual); (void)hipFree(t->d_seq2); (void)hipFree(t->d_qual2);

@@ -119,7 +119,7 @@ uint64_t remove_gaps_workspace_size(uint64_t nrec, uint64_t total)
 
 hipError_t launch_remove_gaps(const LaunchCfg& cfg, const uint8_t* seq, const uint8_t* qual, const uint64_t* offs,
                               uint64_t nrec, uint64_t total, const Table256& is_gap, uint8_t* out_seq, uint8_t* out_qual,
-                              uint64_t* out_offs, void* workspace, uint64_t* result, uint32_t* n_long, hipStream_t s)
+                              uint64_t* out_offs, void* workspace, uint64_t* result, BatchHint* hint, hipStream_t s)
 {
     uint8_t* ws = static_cast<uint8_t*>(workspace);
     uint64_t* totals = reinterpret_cast<uint64_t*>(ws); ws += up256(16);       // [0] records, [1] tiles
@@ -141,7 +141,7 @@ hipError_t launch_remove_gaps(const LaunchCfg& cfg, const uint8_t* seq, const ui
         cls.v[b] = is_gap.v[b] ? 0xFF : 0;
         if (is_gap.v[b] && neutral == 256) neutral = (uint32_t)b;
     }
-    e = launch_count(cfg, seq, offs, nrec, total, cls, 1, neutral, counts, n_long, s);
+    e = launch_count(cfg, seq, offs, nrec, total, cls, 1, neutral, counts, hint, s);
     if (e != hipSuccess) return e;
     e = launch_scan64(counts, nrec, out_offs, part, totals, s);
     if (e != hipSuccess) return e;

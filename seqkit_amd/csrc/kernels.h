@@ -14,8 +14,10 @@ struct Table256 { uint8_t v[256]; };   // passed by value in the kernel argument
 struct StatsPartial { int64_t num, len_sum, gap_sum, len_min, len_max; };
 
 struct LaunchCfg {
-    int logG;            // log2 of lanes per record in the short kernels (0..6)
+    int logG;            // log2 of lanes per record in the short kernels (0..6), from the batch's mean length
     int logG_count;      // the same for the counting kernel (a lane takes more chunks there)
+    int use_hint;        // 1: the short kernels lower logG to what the sampled short records ask for
+                         // (batches of short reads with a few very long records among them)
     uint32_t max_grid;   // optional cap on workgroups of a grid-stride launch (0 = none)
     uint32_t n_cu;       // compute units of the device
     int staged;          // reverse, short records: 1 = LDS-staged kernel, 0 = direct (lane exchange) kernel
@@ -26,19 +28,49 @@ struct LaunchCfg {
     int span_u;          // reverse: 0 = lane-group kernels, 2 or 4 = span kernel with that many chunks per lane
 };
 
-// lut == nullptr: reverse only.  qin/qout == nullptr: no quality plane.
+// What a launch learns about its batch on the device, in one small pass before the kernels proper
+// (launch_prepare): 16 bytes of device scratch per launch in flight.
+struct BatchHint {
+    uint32_t n_long;       // records longer than SKH_LONG_T met by the short kernel (the long-record kernel
+                           // returns at once when it is 0)
+    uint32_t mean_short;   // mean length of the sampled records of at most SKH_LONG_T bytes (~0u: none sampled)
+    uint32_t pad[2];
+};
+
+// log2 of the lanes that serve one record in the short kernels, from a mean record length.
+// Reverse: about three 16-byte chunks per lane (150-base reads -> 4 lanes per record).  Counting: the
+// kernel loops over a lane's chunks and has nothing to hold per chunk, so four to five chunks per
+// lane (measured: reads of ~100 bases 10-17 % faster with 2 lanes per record than with 4; 150 and
+// 250 bases fastest with 4).
+__host__ __device__ inline int lanes_log2_reverse(uint64_t mean)
+{
+    const uint64_t chunks = (mean + 15) / 16 + 1, lanes = (chunks + 2) / 3;
+    int lg = 0;
+    while (lg < 6 && (1ull << lg) < lanes) lg++;
+    return lg;
+}
+__host__ __device__ inline int lanes_log2_count(uint64_t mean)
+{
+    const uint64_t chunks = (mean + 15) / 16 + 1, lanes = chunks <= 9 ? (chunks + 4) / 5 : (chunks + 5) / 5;
+    int lg = 0;
+    while (lg < 6 && (1ull << lg) < lanes) lg++;
+    return lg;
+}
+
+// lut == nullptr: reverse only.  qin/qout == nullptr: no quality plane.  hint: device scratch of this
+// launch (written by the launch itself).
 hipError_t launch_reverse(const LaunchCfg& cfg, const uint8_t* in, uint8_t* out, const uint8_t* qin,
                           uint8_t* qout, const uint64_t* offs, uint64_t nrec, uint64_t total,
-                          const Table256* lut, uint32_t* n_long, hipStream_t st);
+                          const Table256* lut, BatchHint* hint, hipStream_t st);
 hipError_t launch_map_plane(const LaunchCfg& cfg, const uint8_t* in, uint8_t* out, uint64_t total,
                             const Table256& lut, hipStream_t st);
 // neutral: a byte value of no class, or 256 if every byte value has a class.
 hipError_t launch_count(const LaunchCfg& cfg, const uint8_t* seq, const uint64_t* offs, uint64_t nrec,
                         uint64_t total, const Table256& cls, uint32_t nclass, uint32_t neutral,
-                        uint64_t* counts, uint32_t* n_long, hipStream_t st);
+                        uint64_t* counts, BatchHint* hint, hipStream_t st);
 // present: nrec x 8 words, bit (b & 31) of word (b >> 5) set when byte value b occurs in the record
 hipError_t launch_letters(const LaunchCfg& cfg, const uint8_t* seq, const uint64_t* offs, uint64_t nrec, uint64_t total,
-                          uint32_t* present, uint32_t* n_long, hipStream_t st);
+                          uint32_t* present, BatchHint* hint, hipStream_t st);
 // slots: STATS_SLOT_WORDS words of device scratch for this launch (partial gap sums)
 constexpr uint32_t STATS_SLOT_WORDS = 512;
 hipError_t launch_stats(const LaunchCfg& cfg, const uint8_t* seq, const uint64_t* offs, uint64_t nrec,
@@ -121,11 +153,11 @@ hipError_t launch_scan64(const uint64_t* v, uint64_t n, uint64_t* out, uint64_t*
 // ---- gap removal (gaps.hip) -------------------------------------------------------------------
 
 uint64_t remove_gaps_workspace_size(uint64_t nrec, uint64_t total);
-// out planes need room for `total` bytes; out_offs nrec + 1 entries; *result = bytes kept.  n_long:
-// a zeroed flag word for the counting pass.
+// out planes need room for `total` bytes; out_offs nrec + 1 entries; *result = bytes kept.  hint:
+// device scratch for the counting pass.
 hipError_t launch_remove_gaps(const LaunchCfg& cfg, const uint8_t* seq, const uint8_t* qual, const uint64_t* offs,
                               uint64_t nrec, uint64_t total, const Table256& is_gap, uint8_t* out_seq, uint8_t* out_qual,
-                              uint64_t* out_offs, void* workspace, uint64_t* result, uint32_t* n_long, hipStream_t s);
+                              uint64_t* out_offs, void* workspace, uint64_t* result, BatchHint* hint, hipStream_t s);
 
 // ---- subsequences (slices.hip) --------------------------------------------------------------
 

@@ -75,6 +75,115 @@ struct WaveOffsets {
     }
 };
 
+// ------------------------------------------------------------------ batch hint
+//
+// One tiny workgroup ahead of the kernels of a launch: zeroes the launch's long-record counter (what
+// a memset node would do) and, while at it, samples up to 1024 evenly spaced records.  The host picks
+// the lanes per record of the short kernels from the batch's MEAN length, which is all it knows; a few
+// records of megabases among short reads inflate that mean and would leave most lanes of every group
+// idle.  The mean of the sampled records of at most LONG_T bytes corrects it on the device.
+__global__ __launch_bounds__(SKH_BLOCK) void k_prepare(const uint64_t* __restrict__ offs, uint64_t nrec,
+                                                       BatchHint* __restrict__ hint)
+{
+    __shared__ unsigned long long s_sum[SKH_BLOCK / 64];
+    __shared__ uint32_t s_n[SKH_BLOCK / 64];
+    constexpr uint32_t PER = 4;
+    const uint64_t nsample = nrec < PER * SKH_BLOCK ? nrec : PER * SKH_BLOCK;
+    unsigned long long sum = 0;
+    uint32_t n = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < PER; k++) {
+        const uint64_t i = threadIdx.x + (uint64_t)k * SKH_BLOCK;
+        if (i < nsample) {
+            const uint64_t r = (nrec / nsample) * i + (nrec % nsample) * i / nsample;   // = i * nrec / nsample, no overflow
+            const uint64_t len = offs[r + 1] - offs[r];
+            if (len <= SKH_LONG_T) { sum += len; n++; }
+        }
+    }
+    for (uint32_t m = 1; m < 64; m <<= 1) {
+        sum += __shfl_xor(sum, m);
+        n += __shfl_xor(n, m);
+    }
+    if ((threadIdx.x & 63) == 0) { s_sum[threadIdx.x >> 6] = sum; s_n[threadIdx.x >> 6] = n; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < SKH_BLOCK / 64; w++) { sum += s_sum[w]; n += s_n[w]; }
+        hint->n_long = 0;
+        hint->mean_short = n ? (uint32_t)(sum / n) : ~0u;
+        hint->pad[0] = hint->pad[1] = 0;
+    }
+}
+
+// log2 of the lanes per record a short kernel works with: the host's choice, lowered to what the
+// sampled short records ask for (never raised: the grid was sized for the host's choice).
+template <bool COUNT>
+__device__ __forceinline__ int hinted_logG(int logG_host, const BatchHint* hint, int use_hint)
+{
+    if (!use_hint) return logG_host;
+    const uint32_t mean = __builtin_amdgcn_readfirstlane(hint->mean_short);
+    if (mean == ~0u) return logG_host;
+    const int lg = COUNT ? lanes_log2_count(mean) : lanes_log2_reverse(mean);
+    return lg < logG_host ? lg : logG_host;
+}
+
+// ------------------------------------------------------------------ long records
+//
+// Records longer than LONG_T are served by workgroups that own one aligned RUN of the plane each
+// (the grid covers the plane once, in address order).  A workgroup finds the record holding the first
+// byte of its run with one 64-ary search, then walks the offsets forward 256 at a time through LDS
+// (one load per thread) looking for long records: in a chromosome-scale batch the first slice settles
+// it, among short reads a run of 128 KiB costs a handful of slices, and no window of the plane pays a
+// search of its own.  f(r, s, e) is called by all threads together for every long record [s, e) that
+// overlaps [t0, t1), in order.
+constexpr uint64_t LONG_RUN = 4 * SKH_TILE;          // bytes of plane per workgroup of the long-record kernels
+
+struct WalkLds {
+    uint64_t off[SKH_BLOCK + 1];
+    uint32_t first;
+};
+
+template <typename F>
+__device__ __forceinline__ void for_each_long(const uint64_t* __restrict__ offs, uint64_t nrec, uint64_t t0,
+                                              uint64_t t1, WalkLds& W, F&& f)
+{
+    uint64_t r = find_record(offs, nrec, t0);            // the same in every wavefront
+    while (true) {
+        __syncthreads();                                  // the slice of the iteration before is done with
+        {
+            const uint64_t idx = r + threadIdx.x;
+            W.off[threadIdx.x] = idx <= nrec ? offs[idx] : ~0ull;
+            if (threadIdx.x == 0) {
+                const uint64_t idx2 = r + SKH_BLOCK;
+                W.off[SKH_BLOCK] = idx2 <= nrec ? offs[idx2] : ~0ull;
+            }
+        }
+        __syncthreads();
+        const uint64_t a = W.off[threadIdx.x], b = W.off[threadIdx.x + 1];
+        const bool is_long = b != ~0ull && a < t1 && b - a > SKH_LONG_T;
+        uint32_t from = 0;
+        bool done = false;
+        while (true) {
+            if (threadIdx.x == 0) W.first = SKH_BLOCK;
+            __syncthreads();
+            const unsigned long long m = __ballot(is_long && threadIdx.x >= from);
+            if (m != 0 && (threadIdx.x & 63) == 0)
+                atomicMin(&W.first, (threadIdx.x & ~63u) + (uint32_t)__builtin_ctzll(m));
+            __syncthreads();
+            const uint32_t i = W.first;
+            if (i == SKH_BLOCK) break;
+            const uint64_t s = W.off[i], e = W.off[i + 1];
+            f(r + i, s, e);
+            if (e >= t1) { done = true; break; }
+            from = i + 1;
+            __syncthreads();                              // W.first is rewritten
+        }
+        if (done) return;
+        const uint64_t last = W.off[SKH_BLOCK];
+        if (last == ~0ull || last >= t1) return;          // the slice reached the end of the batch or of the run
+        r += SKH_BLOCK;
+    }
+}
+
 // ------------------------------------------------------------------ reverse (+complement)
 //
 // out[p] = lut[in[s + e - 1 - p]] for every byte p of a record [s, e).
@@ -309,8 +418,9 @@ __device__ __forceinline__ void reverse_batch(const RevPlanes& P, const RevLds& 
 // Nothing crosses lanes, so any G gives the same bytes.
 template <bool COMP, bool FASTQ>
 __global__ __launch_bounds__(SKH_BLOCK) void k_reverse_short(RevPlanes P, uint64_t nrec, Table256 lut,
-                                                             int logG, uint32_t* __restrict__ n_long)
+                                                             int logG, BatchHint* __restrict__ hint)
 {
+    uint32_t* n_long = &hint->n_long;
     __shared__ RevLds L;
     rev_lds_init<COMP>(L, lut);
     constexpr int U = 3;
@@ -425,17 +535,21 @@ __device__ __forceinline__ uint4 lds_window_reversed(const uint8_t* slot, uint32
 template <bool COMP>
 __global__ __launch_bounds__(SKH_BLOCK) void k_reverse_staged(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
                                                               const uint64_t* __restrict__ offs, uint64_t total,
-                                                              uint64_t nrec, Table256 lut, int logG, uint32_t steps,
-                                                              uint32_t* __restrict__ n_long)
+                                                              uint64_t nrec, Table256 lut, int logG_host, uint32_t steps,
+                                                              BatchHint* __restrict__ hint, int use_hint)
 {
     __shared__ StageLds S;
     rev_lds_init<COMP>(S.tab, lut);
+    uint32_t* n_long = &hint->n_long;
+    const int logG = hinted_logG<false>(logG_host, hint, use_hint);
     const uint32_t G = 1u << logG, j = threadIdx.x & (G - 1);
     const uint32_t lane = threadIdx.x & 63, GW = 64u >> logG, g = lane >> logG;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint64_t padded = (total + 15) & ~15ull;
     // Workgroup b serves the `steps` * ST_WAVES consecutive steps from b * steps * ST_WAVES on,
-    // its wavefronts interleaved step by step.  The grid covers the batch once: workgroups
+    // its wavefronts interleaved step by step.  (With fewer lanes per record than the host sized
+    // the grid for, a step holds more records and the last workgroups of the grid find nothing
+    // left to do.)  The grid covers the batch once: workgroups
     // start in index order, so the chip sweeps the planes front to back in one narrow window,
     // which the memory system rewards (a grid-stride loop over resident workgroups keeps
     // thousands of distant streams open and is ~10% slower on the same work).
@@ -455,7 +569,7 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_reverse_staged(const uint8_t* __r
     struct Bounds { uint64_t first, last; };
     auto bounds_of = [&](uint64_t r0) {
         r0 = r0 < rec_end ? r0 : rec_first;
-        const uint64_t hi = r0 + GW < nrec ? r0 + GW : nrec;
+        const uint64_t hi = r0 + GW < rec_end ? r0 + GW : rec_end;
         Bounds bd;
         bd.first = r0 ? coffs[r0 - 1] : 0;
         bd.last = coffs[hi];
@@ -465,7 +579,7 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_reverse_staged(const uint8_t* __r
     auto issue = [&](uint64_t r0, const Bounds& bd, uint32_t b) {
         r0 = r0 < rec_end ? r0 : rec_first;
         const uint64_t ob = r0 ? r0 - 1 : 0;         // first offset of the slice
-        const uint64_t hi = r0 + GW < nrec ? r0 + GW : nrec;
+        const uint64_t hi = r0 + GW < rec_end ? r0 + GW : rec_end;
         uint64_t a0, n;
         stretch_range(bd.first, bd.last, padded, a0, n);
         const uint32_t nb = n < ST_BYTES ? (uint32_t)n : ST_BYTES;
@@ -520,13 +634,13 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_reverse_staged(const uint8_t* __r
         const uint32_t bi = g + i0;
         const uint64_t rec = rec0 + g;
         uint64_t sprev = 0, s = 0, e = 0;
-        if (rec < nrec) {
+        if (rec < rec_end) {
             s = L[bi];
             e = rec + 1 == nrec ? total : L[bi + 1];
             sprev = rec ? L[bi - 1] : 0;
         }
         // the step as issue() saw it: its records end at e_last, its stretch is [a0, a0 + nst)
-        const uint64_t hi = rec0 + GW < nrec ? rec0 + GW : nrec;
+        const uint64_t hi = rec0 + GW < rec_end ? rec0 + GW : rec_end;
         const uint64_t s_first = L[i0], e_last = hi == nrec ? total : L[i0 + (uint32_t)(hi - rec0)];
         uint64_t a0, nst;
         stretch_range(rec0 ? L[0] : 0, e_last, padded, a0, nst);
@@ -632,45 +746,33 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_reverse_staged(const uint8_t* __r
     wait_vmcnt<0>();     // nothing may land in LDS after the wavefront has gone
 }
 
-// Long records: one aligned TILE-byte window of the plane per workgroup iteration.
-// Only the record holding the window's first byte and the record holding its last
-// byte can be longer than TILE, so two searches find every long record it touches.
+// Long records: one aligned run of LONG_RUN bytes of the plane per workgroup (see for_each_long).
 template <bool COMP, bool FASTQ>
 __global__ __launch_bounds__(SKH_BLOCK) void k_reverse_tiles(RevPlanes P, uint64_t nrec, Table256 lut,
-                                                             const uint32_t* __restrict__ n_long)
+                                                             const BatchHint* __restrict__ hint)
 {
-    if (*n_long == 0) return;
+    if (hint->n_long == 0) return;
     __shared__ RevLds L;
+    __shared__ WalkLds W;
     rev_lds_init<COMP>(L, lut);
     constexpr int U = 4;
     const uint64_t total = P.total;
-    const uint64_t ntiles = (total + SKH_TILE - 1) / SKH_TILE;
-    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const uint64_t t0 = tile * SKH_TILE;
-        const uint64_t t1 = t0 + SKH_TILE;                       // exclusive, may exceed total
-        const uint64_t last = (t1 < total ? t1 : total) - 1;     // last real byte of the window
-        const uint64_t r_lo = find_record(P.offs, nrec, t0);
-        // (a record that reaches beyond the window is the last one too: no second search)
-        const uint64_t r_hi = P.offs[r_lo + 1] > last ? r_lo : find_record(P.offs, nrec, last);
-#pragma unroll 1
-        for (int c = 0; c < 2; c++) {
-            if (c == 1 && r_hi == r_lo) break;
-            const uint64_t r = c == 0 ? r_lo : r_hi;
-            const uint64_t s = P.offs[r], e = P.offs[r + 1];
-            if (e - s <= SKH_LONG_T) continue;
-            const uint64_t sprev = r ? P.offs[r - 1] : 0;
-            const uint64_t o0 = s & ~15ull;
-            const uint32_t n_own = (uint32_t)((e - o0) >> 4);    // < 2^28 chunks: records < 4 GiB
-            // owned chunks of the record that lie in this window: indices [k0, k1)
-            const uint32_t k0 = o0 >= t0 ? 0u : (uint32_t)((t0 - o0) >> 4);
-            const uint64_t own_end = o0 + 16ull * n_own;
-            const uint32_t k1 = own_end <= t1 ? n_own : (uint32_t)((t1 - o0) >> 4);
-            for (uint32_t kb = k0; kb < k1; kb += U * SKH_BLOCK)
-                reverse_batch<COMP, FASTQ, U, true>(P, L, r, sprev, s, e, kb + threadIdx.x, SKH_BLOCK, k1);
-            if (e == total && (e & 15) != 0 && own_end >= t0 && own_end < t1 && threadIdx.x == 0)
-                reverse_chunk_generic<COMP, FASTQ>(P.in, P.out, P.qin, P.qout, P.offs, r, total, own_end, L.lut);
-        }
-    }
+    const uint64_t t0 = (uint64_t)blockIdx.x * LONG_RUN;
+    if (t0 >= total) return;
+    const uint64_t t1 = t0 + LONG_RUN;                           // exclusive, may exceed total
+    for_each_long(P.offs, nrec, t0, t1 < total ? t1 : total, W, [&](uint64_t r, uint64_t s, uint64_t e) {
+        const uint64_t sprev = r ? P.offs[r - 1] : 0;
+        const uint64_t o0 = s & ~15ull;
+        const uint32_t n_own = (uint32_t)((e - o0) >> 4);        // < 2^28 chunks: records < 4 GiB
+        // owned chunks of the record that lie in this run: indices [k0, k1)
+        const uint32_t k0 = o0 >= t0 ? 0u : (uint32_t)((t0 - o0) >> 4);
+        const uint64_t own_end = o0 + 16ull * n_own;
+        const uint32_t k1 = own_end <= t1 ? n_own : (uint32_t)((t1 - o0) >> 4);
+        for (uint32_t kb = k0; kb < k1; kb += U * SKH_BLOCK)
+            reverse_batch<COMP, FASTQ, U, true>(P, L, r, sprev, s, e, kb + threadIdx.x, SKH_BLOCK, k1);
+        if (e == total && (e & 15) != 0 && own_end >= t0 && own_end < t1 && threadIdx.x == 0)
+            reverse_chunk_generic<COMP, FASTQ>(P.in, P.out, P.qin, P.qout, P.offs, r, total, own_end, L.lut);
+    });
 }
 
 // ---- span form: lanes own consecutive output chunks of the plane ------------------------
@@ -973,11 +1075,13 @@ __device__ __forceinline__ uint32_t field16(const uint32_t* acc16, uint32_t c)
 template <int NW>
 __global__ __launch_bounds__(SKH_BLOCK) void k_count_short(
     const uint8_t* __restrict__ seq, const uint64_t* __restrict__ offs, uint64_t nrec, uint64_t total,
-    Table256 cls, uint32_t nclass, int logG, uint32_t steps, uint32_t neutral, uint64_t* __restrict__ counts,
-    uint32_t* __restrict__ n_long)
+    Table256 cls, uint32_t nclass, int logG_host, uint32_t steps, uint32_t neutral, uint64_t* __restrict__ counts,
+    BatchHint* __restrict__ hint, int use_hint)
 {
     __shared__ CountLds<NW> L;
     count_lds_init<NW>(L, cls);
+    uint32_t* n_long = &hint->n_long;
+    const int logG = hinted_logG<true>(logG_host, hint, use_hint);
     constexpr int U = 3;
     const bool has_neutral = neutral < 256u;
     const uint32_t neutral4 = (neutral & 0xffu) * 0x01010101u;
@@ -998,7 +1102,7 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_count_short(
         if (next0 < rec_end) nwo.load(offs, nrec, total, next0, GW, lane);
         const uint64_t rec = rec0 + g;
         const uint64_t s = wo.get(g + 1, GW), e = wo.get(g + 2, GW);
-        const uint64_t len = e - s;
+        const uint64_t len = rec < rec_end ? e - s : 0;     // records past the range belong to the next workgroup
         uint32_t acc16[2 * NW];
 #pragma unroll
         for (int i = 0; i < 2 * NW; i++) acc16[i] = 0;
@@ -1037,7 +1141,7 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_count_short(
                 for (int i = 0; i < 2 * NW; i++) acc16[i] += __shfl_xor(acc16[i], m);
             }
         }
-        if (rec < nrec)
+        if (rec < rec_end)
             for (uint32_t c = j; c < nclass; c += G) counts[rec * nclass + c] = field16<NW>(acc16, c);
         if (next0 >= rec_end) break;
         rec0 = next0;
@@ -1045,59 +1149,66 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_count_short(
     }
 }
 
+// Long records: a workgroup owns one aligned run of LONG_RUN bytes of the plane and counts the part of
+// every long record inside it.  All chunk loads of a batch (8 per lane = 32 KiB per workgroup) are
+// issued before the first table lookup; a record's part of the run is summed in registers and leaves
+// as one atomic per class.
 template <int NW>
 __global__ __launch_bounds__(SKH_BLOCK) void k_count_tiles(
     const uint8_t* __restrict__ seq, const uint64_t* __restrict__ offs, uint64_t nrec, uint64_t total,
     Table256 cls, uint32_t nclass, uint32_t neutral, uint64_t* __restrict__ counts,
-    const uint32_t* __restrict__ n_long)
+    const BatchHint* __restrict__ hint)
 {
-    if (*n_long == 0) return;
+    if (hint->n_long == 0) return;
     __shared__ CountLds<NW> L;
+    __shared__ WalkLds W;
     __shared__ uint32_t s_part[SKH_BLOCK / 64][4 * NW];
     count_lds_init<NW>(L, cls);
     const bool has_neutral = neutral < 256u;
     const uint32_t neutral4 = (neutral & 0xffu) * 0x01010101u;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint64_t ntiles = (total + SKH_TILE - 1) / SKH_TILE;
-    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const uint64_t t0 = tile * SKH_TILE;
-        const uint64_t t1 = t0 + SKH_TILE;
-        const uint64_t last = (t1 < total ? t1 : total) - 1;
-        const uint64_t r_lo = find_record(offs, nrec, t0);
-        const uint64_t r_hi = offs[r_lo + 1] > last ? r_lo : find_record(offs, nrec, last);
-#pragma unroll 1
-        for (int c = 0; c < 2; c++) {
-            if (c == 1 && r_hi == r_lo) break;
-            const uint64_t r = c == 0 ? r_lo : r_hi;
-            const uint64_t s = offs[r], e = offs[r + 1];
-            if (e - s <= SKH_LONG_T) continue;                 // block-uniform
-            const uint64_t a = s & ~15ull, b = (e + 15) & ~15ull;
-            const uint64_t c0 = a > t0 ? a : t0, c1 = b < t1 ? b : t1;
-            uint32_t acc8[NW], acc16[2 * NW];
+    const uint64_t t0 = (uint64_t)blockIdx.x * LONG_RUN;
+    if (t0 >= total) return;
+    const uint64_t t1 = t0 + LONG_RUN;
+    constexpr int UB = 8;                                      // chunks per lane in flight
+    static_assert(LONG_RUN / SKH_BLOCK <= 512, "16-bit fields: 64 lanes x bytes per lane must stay below 65536");
+    for_each_long(offs, nrec, t0, t1 < total ? t1 : total, W, [&](uint64_t r, uint64_t s, uint64_t e) {
+        const uint64_t a = s & ~15ull, b = (e + 15) & ~15ull;
+        const uint64_t c0 = a > t0 ? a : t0, c1 = b < t1 ? b : t1;
+        uint32_t acc8[NW], acc16[2 * NW];
 #pragma unroll
-            for (int i = 0; i < NW; i++) acc8[i] = 0;
+        for (int i = 0; i < NW; i++) acc8[i] = 0;
 #pragma unroll
-            for (int i = 0; i < 2 * NW; i++) acc16[i] = 0;
-            // TILE / (16 * BLOCK) = 8 chunks = 128 bytes per lane: 8-bit fields hold it
-            for (uint64_t o = c0 + 16ull * threadIdx.x; o < c1; o += 16ull * SKH_BLOCK)
-                count_chunk<NW>(seq, s, e, o, L, neutral4, has_neutral, acc8);
-            widen<NW>(acc8, acc16);
-            for (uint32_t m = 1; m < 64; m <<= 1) {            // <= 64 * 128 per field
+        for (int i = 0; i < 2 * NW; i++) acc16[i] = 0;
+        for (uint64_t ob = c0 + 16ull * threadIdx.x; ob < c1; ob += 16ull * SKH_BLOCK * UB) {
+            uint4 V[UB];
 #pragma unroll
-                for (int i = 0; i < 2 * NW; i++) acc16[i] += __shfl_xor(acc16[i], m);
+            for (int u = 0; u < UB; u++) {                     // a lane without a chunk re-reads its first one
+                const uint64_t o = ob + 16ull * SKH_BLOCK * u;
+                V[u] = ld16(seq + (o < c1 ? o : ob));
             }
-            __syncthreads();                                   // s_part free again
-            if (lane < nclass) s_part[wave][lane] = field16<NW>(acc16, lane);
-            __syncthreads();
-            if (threadIdx.x < nclass) {
-                uint64_t sum = 0;
 #pragma unroll
-                for (int w = 0; w < SKH_BLOCK / 64; w++) sum += s_part[w][threadIdx.x];
-                if (sum) atomicAdd(reinterpret_cast<unsigned long long*>(&counts[r * nclass + threadIdx.x]),
-                                   (unsigned long long)sum);
+            for (int u = 0; u < UB; u++) {
+                const uint64_t o = ob + 16ull * SKH_BLOCK * u;
+                if (o < c1) count_loaded<NW>(V[u], s, e, o, L, neutral4, has_neutral, acc8);
             }
+            widen<NW>(acc8, acc16);                            // 8 chunks = 128 bytes per 8-bit field at most
         }
-    }
+        for (uint32_t m = 1; m < 64; m <<= 1) {                // <= 64 * 512 per field
+#pragma unroll
+            for (int i = 0; i < 2 * NW; i++) acc16[i] += __shfl_xor(acc16[i], m);
+        }
+        __syncthreads();                                       // s_part free again
+        if (lane < nclass) s_part[wave][lane] = field16<NW>(acc16, lane);
+        __syncthreads();
+        if (threadIdx.x < nclass) {
+            uint64_t sum = 0;
+#pragma unroll
+            for (int w = 0; w < SKH_BLOCK / 64; w++) sum += s_part[w][threadIdx.x];
+            if (sum) atomicAdd(reinterpret_cast<unsigned long long*>(&counts[r * nclass + threadIdx.x]),
+                               (unsigned long long)sum);
+        }
+    });
 }
 
 // ------------------------------------------------------------------ letters present
@@ -1124,8 +1235,9 @@ __device__ __forceinline__ void set_bits16(uint4 v, int lo, int hi, uint32_t* m)
 __global__ __launch_bounds__(SKH_BLOCK) void k_letters_short(const uint8_t* __restrict__ seq,
                                                              const uint64_t* __restrict__ offs, uint64_t nrec,
                                                              uint64_t total, int logG, uint32_t* __restrict__ present,
-                                                             uint32_t* __restrict__ n_long)
+                                                             BatchHint* __restrict__ hint)
 {
+    uint32_t* n_long = &hint->n_long;
     const uint32_t G = 1u << logG, j = threadIdx.x & (G - 1);
     const uint32_t lane = threadIdx.x & 63, GW = 64u >> logG, g = lane >> logG;
     const uint64_t stride = (uint64_t)gridDim.x * (SKH_BLOCK / 64) * GW;
@@ -1168,48 +1280,39 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_letters_short(const uint8_t* __re
 __global__ __launch_bounds__(SKH_BLOCK) void k_letters_tiles(const uint8_t* __restrict__ seq,
                                                              const uint64_t* __restrict__ offs, uint64_t nrec,
                                                              uint64_t total, uint32_t* __restrict__ present,
-                                                             const uint32_t* __restrict__ n_long)
+                                                             const BatchHint* __restrict__ hint)
 {
-    if (*n_long == 0) return;
+    if (hint->n_long == 0) return;
     __shared__ uint32_t s_m[8];
-    const uint64_t ntiles = (total + SKH_TILE - 1) / SKH_TILE;
-    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const uint64_t t0 = tile * SKH_TILE;
-        const uint64_t t1 = t0 + SKH_TILE;
-        const uint64_t last = (t1 < total ? t1 : total) - 1;
-        const uint64_t r_lo = find_record(offs, nrec, t0);
-        const uint64_t r_hi = offs[r_lo + 1] > last ? r_lo : find_record(offs, nrec, last);
-#pragma unroll 1
-        for (int c = 0; c < 2; c++) {
-            if (c == 1 && r_hi == r_lo) break;
-            const uint64_t r = c == 0 ? r_lo : r_hi;
-            const uint64_t s = offs[r], e = offs[r + 1];
-            if (e - s <= SKH_LONG_T) continue;                 // block-uniform
-            const uint64_t a = s & ~15ull, b = (e + 15) & ~15ull;
-            const uint64_t c0 = a > t0 ? a : t0, c1 = b < t1 ? b : t1;
-            uint32_t m[8];
+    __shared__ WalkLds W;
+    const uint64_t t0 = (uint64_t)blockIdx.x * LONG_RUN;
+    if (t0 >= total) return;
+    const uint64_t t1 = t0 + LONG_RUN;
+    for_each_long(offs, nrec, t0, t1 < total ? t1 : total, W, [&](uint64_t r, uint64_t s, uint64_t e) {
+        const uint64_t a = s & ~15ull, b = (e + 15) & ~15ull;
+        const uint64_t c0 = a > t0 ? a : t0, c1 = b < t1 ? b : t1;
+        uint32_t m[8];
 #pragma unroll
-            for (int i = 0; i < 8; i++) m[i] = 0;
-            for (uint64_t o = c0 + 16ull * threadIdx.x; o < c1; o += 16ull * SKH_BLOCK) {
-                const int lo = s > o ? (int)(s - o) : 0;
-                const int hi = e < o + 16 ? (int)(e - o) : 16;
-                set_bits16(ld16(seq + o), lo, hi, m);
-            }
-            for (uint32_t d = 1; d < 64; d <<= 1) {
-#pragma unroll
-                for (int i = 0; i < 8; i++) m[i] |= __shfl_xor(m[i], d);
-            }
-            __syncthreads();                                   // s_m free again
-            if (threadIdx.x < 8) s_m[threadIdx.x] = 0;
-            __syncthreads();
-            if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-                for (int i = 0; i < 8; i++) if (m[i]) atomicOr(&s_m[i], m[i]);
-            }
-            __syncthreads();
-            if (threadIdx.x < 8 && s_m[threadIdx.x]) atomicOr(&present[r * 8 + threadIdx.x], s_m[threadIdx.x]);
+        for (int i = 0; i < 8; i++) m[i] = 0;
+        for (uint64_t o = c0 + 16ull * threadIdx.x; o < c1; o += 16ull * SKH_BLOCK) {
+            const int lo = s > o ? (int)(s - o) : 0;
+            const int hi = e < o + 16 ? (int)(e - o) : 16;
+            set_bits16(ld16(seq + o), lo, hi, m);
         }
-    }
+        for (uint32_t d = 1; d < 64; d <<= 1) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) m[i] |= __shfl_xor(m[i], d);
+        }
+        __syncthreads();                                   // s_m free again
+        if (threadIdx.x < 8) s_m[threadIdx.x] = 0;
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) if (m[i]) atomicOr(&s_m[i], m[i]);
+        }
+        __syncthreads();
+        if (threadIdx.x < 8 && s_m[threadIdx.x]) atomicOr(&present[r * 8 + threadIdx.x], s_m[threadIdx.x]);
+    });
 }
 
 // ------------------------------------------------------------------ stats totals
@@ -1438,11 +1541,20 @@ static hipError_t launch_reverse_span_t(const LaunchCfg& cfg, const RevPlanes& P
     return hipGetLastError();
 }
 
+// workgroups of a long-record kernel: one per run of the plane
+static inline uint64_t long_runs(uint64_t total) { return (total + LONG_RUN - 1) / LONG_RUN; }
+
+static hipError_t launch_prepare(const uint64_t* offs, uint64_t nrec, BatchHint* hint, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_prepare, dim3(1), dim3(SKH_BLOCK), 0, st, offs, nrec, hint);
+    return hipGetLastError();
+}
+
 template <bool COMP, bool FASTQ>
 static hipError_t launch_reverse_t(const LaunchCfg& cfg, const uint8_t* in, uint8_t* out,
                                    const uint8_t* qin, uint8_t* qout, const uint64_t* offs,
                                    uint64_t nrec, uint64_t total, const Table256& lut,
-                                   uint32_t* n_long, hipStream_t st)
+                                   BatchHint* hint, hipStream_t st)
 {
     const RevPlanes P{in, out, qin, qout, offs, total};
     if (cfg.span_u && !FASTQ) return launch_reverse_span_t<COMP>(cfg, P, nrec, lut, st);
@@ -1452,39 +1564,52 @@ static hipError_t launch_reverse_t(const LaunchCfg& cfg, const uint8_t* in, uint
         const uint64_t g1 = (nrec + per_block - 1) / per_block;
         if (g1 > 0x7fffffffull) return hipErrorInvalidValue;
         hipLaunchKernelGGL((k_reverse_staged<COMP>), dim3((uint32_t)g1), dim3(SKH_BLOCK), 0, st, P.in, P.out, P.offs,
-                           P.total, nrec, lut, cfg.logG, steps, n_long);
+                           P.total, nrec, lut, cfg.logG, steps, hint, cfg.use_hint);
     } else {
         const uint32_t g1 = grid_for(nrec, SKH_BLOCK >> cfg.logG, resident_cap(k_reverse_short<COMP, FASTQ>, cfg));
         hipLaunchKernelGGL((k_reverse_short<COMP, FASTQ>), dim3(g1), dim3(SKH_BLOCK), 0, st, P, nrec, lut,
-                           cfg.logG, n_long);
+                           cfg.logG, hint);
     }
-    const uint32_t g2 = grid_for((total + SKH_TILE - 1) / SKH_TILE, 1, resident_cap(k_reverse_tiles<COMP, FASTQ>, cfg));
-    hipLaunchKernelGGL((k_reverse_tiles<COMP, FASTQ>), dim3(g2), dim3(SKH_BLOCK), 0, st, P, nrec, lut,
-                       n_long);
+    const uint64_t g2 = long_runs(total);
+    if (g2 > 0x7fffffffull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((k_reverse_tiles<COMP, FASTQ>), dim3((uint32_t)g2), dim3(SKH_BLOCK), 0, st, P, nrec, lut,
+                       hint);
     return hipGetLastError();
 }
 
-hipError_t launch_reverse(const LaunchCfg& cfg, const uint8_t* in, uint8_t* out, const uint8_t* qin,
-                          uint8_t* qout, const uint64_t* offs, uint64_t nrec, uint64_t total,
-                          const Table256* lut, uint32_t* n_long, hipStream_t st)
+static hipError_t reverse_planes(const LaunchCfg& cfg, const uint8_t* in, uint8_t* out, const uint8_t* qin,
+                                 uint8_t* qout, const uint64_t* offs, uint64_t nrec, uint64_t total,
+                                 const Table256* lut, BatchHint* hint, hipStream_t st)
 {
     static const Table256 ident = [] { Table256 t; for (int i = 0; i < 256; i++) t.v[i] = (uint8_t)i; return t; }();
     bool fastq = qin != nullptr;
     if (fastq && (!cfg.fuse_fastq || cfg.span_u)) {
         // the two planes as two launches: half the registers per lane, twice the resident
         // wavefronts; the offsets are read twice, which is cheaper than the lost occupancy
-        hipError_t e = launch_reverse(cfg, qin, qout, nullptr, nullptr, offs, nrec, total, nullptr, n_long, st);
+        // (the long-record counter keeps counting: only "zero or not" is looked at)
+        hipError_t e = reverse_planes(cfg, qin, qout, nullptr, nullptr, offs, nrec, total, nullptr, hint, st);
         if (e != hipSuccess) return e;
         fastq = false;
         qin = nullptr;
         qout = nullptr;
     }
     if (lut) {
-        return fastq ? launch_reverse_t<true, true>(cfg, in, out, qin, qout, offs, nrec, total, *lut, n_long, st)
-                     : launch_reverse_t<true, false>(cfg, in, out, qin, qout, offs, nrec, total, *lut, n_long, st);
+        return fastq ? launch_reverse_t<true, true>(cfg, in, out, qin, qout, offs, nrec, total, *lut, hint, st)
+                     : launch_reverse_t<true, false>(cfg, in, out, qin, qout, offs, nrec, total, *lut, hint, st);
     }
-    return fastq ? launch_reverse_t<false, true>(cfg, in, out, qin, qout, offs, nrec, total, ident, n_long, st)
-                 : launch_reverse_t<false, false>(cfg, in, out, qin, qout, offs, nrec, total, ident, n_long, st);
+    return fastq ? launch_reverse_t<false, true>(cfg, in, out, qin, qout, offs, nrec, total, ident, hint, st)
+                 : launch_reverse_t<false, false>(cfg, in, out, qin, qout, offs, nrec, total, ident, hint, st);
+}
+
+hipError_t launch_reverse(const LaunchCfg& cfg, const uint8_t* in, uint8_t* out, const uint8_t* qin,
+                          uint8_t* qout, const uint64_t* offs, uint64_t nrec, uint64_t total,
+                          const Table256* lut, BatchHint* hint, hipStream_t st)
+{
+    if (!cfg.span_u) {                       // the span kernel serves every record itself
+        hipError_t e = launch_prepare(offs, nrec, hint, st);
+        if (e != hipSuccess) return e;
+    }
+    return reverse_planes(cfg, in, out, qin, qout, offs, nrec, total, lut, hint, st);
 }
 
 hipError_t launch_map_plane(const LaunchCfg& cfg, const uint8_t* in, uint8_t* out, uint64_t total,
@@ -1497,36 +1622,39 @@ hipError_t launch_map_plane(const LaunchCfg& cfg, const uint8_t* in, uint8_t* ou
 
 hipError_t launch_count(const LaunchCfg& cfg, const uint8_t* seq, const uint64_t* offs, uint64_t nrec,
                         uint64_t total, const Table256& cls, uint32_t nclass, uint32_t neutral,
-                        uint64_t* counts, uint32_t* n_long, hipStream_t st)
+                        uint64_t* counts, BatchHint* hint, hipStream_t st)
 {
-    const uint64_t ntile = (total + SKH_TILE - 1) / SKH_TILE;
     const uint32_t steps = cfg.count_steps ? cfg.count_steps : 3;     // steps per wavefront (2-3 measured 1-4 % ahead of 4 and of 1 on reads of 100-250 bases)
     const uint64_t per_block = (uint64_t)steps * (SKH_BLOCK >> cfg.logG_count);
     const uint64_t g1 = (nrec + per_block - 1) / per_block;
-    if (g1 > 0x7fffffffull) return hipErrorInvalidValue;
+    const uint64_t g2 = long_runs(total);
+    if (g1 > 0x7fffffffull || g2 > 0x7fffffffull) return hipErrorInvalidValue;
+    hipError_t e = launch_prepare(offs, nrec, hint, st);
+    if (e != hipSuccess) return e;
     if (nclass <= 4) {
-        const uint32_t g2 = grid_for(ntile, 1, resident_cap(k_count_tiles<1>, cfg));
         hipLaunchKernelGGL((k_count_short<1>), dim3((uint32_t)g1), dim3(SKH_BLOCK), 0, st, seq, offs, nrec, total,
-                           cls, nclass, cfg.logG_count, steps, neutral, counts, n_long);
-        hipLaunchKernelGGL((k_count_tiles<1>), dim3(g2), dim3(SKH_BLOCK), 0, st, seq, offs, nrec, total,
-                           cls, nclass, neutral, counts, n_long);
+                           cls, nclass, cfg.logG_count, steps, neutral, counts, hint, cfg.use_hint);
+        if (g2) hipLaunchKernelGGL((k_count_tiles<1>), dim3((uint32_t)g2), dim3(SKH_BLOCK), 0, st, seq, offs, nrec, total,
+                                   cls, nclass, neutral, counts, hint);
     } else {
-        const uint32_t g2 = grid_for(ntile, 1, resident_cap(k_count_tiles<2>, cfg));
         hipLaunchKernelGGL((k_count_short<2>), dim3((uint32_t)g1), dim3(SKH_BLOCK), 0, st, seq, offs, nrec, total,
-                           cls, nclass, cfg.logG_count, steps, neutral, counts, n_long);
-        hipLaunchKernelGGL((k_count_tiles<2>), dim3(g2), dim3(SKH_BLOCK), 0, st, seq, offs, nrec, total,
-                           cls, nclass, neutral, counts, n_long);
+                           cls, nclass, cfg.logG_count, steps, neutral, counts, hint, cfg.use_hint);
+        if (g2) hipLaunchKernelGGL((k_count_tiles<2>), dim3((uint32_t)g2), dim3(SKH_BLOCK), 0, st, seq, offs, nrec, total,
+                                   cls, nclass, neutral, counts, hint);
     }
     return hipGetLastError();
 }
 
 hipError_t launch_letters(const LaunchCfg& cfg, const uint8_t* seq, const uint64_t* offs, uint64_t nrec, uint64_t total,
-                          uint32_t* present, uint32_t* n_long, hipStream_t st)
+                          uint32_t* present, BatchHint* hint, hipStream_t st)
 {
+    const uint64_t g2 = long_runs(total);
+    if (g2 > 0x7fffffffull) return hipErrorInvalidValue;
+    hipError_t e = launch_prepare(offs, nrec, hint, st);
+    if (e != hipSuccess) return e;
     const uint32_t g1 = grid_for(nrec, SKH_BLOCK >> cfg.logG, cfg.n_cu * 8);
-    hipLaunchKernelGGL(k_letters_short, dim3(g1), dim3(SKH_BLOCK), 0, st, seq, offs, nrec, total, cfg.logG, present, n_long);
-    const uint32_t g2 = grid_for((total + SKH_TILE - 1) / SKH_TILE, 1, cfg.n_cu * 8);
-    hipLaunchKernelGGL(k_letters_tiles, dim3(g2), dim3(SKH_BLOCK), 0, st, seq, offs, nrec, total, present, n_long);
+    hipLaunchKernelGGL(k_letters_short, dim3(g1), dim3(SKH_BLOCK), 0, st, seq, offs, nrec, total, cfg.logG, present, hint);
+    if (g2) hipLaunchKernelGGL(k_letters_tiles, dim3((uint32_t)g2), dim3(SKH_BLOCK), 0, st, seq, offs, nrec, total, present, hint);
     return hipGetLastError();
 }
 

@@ -96,6 +96,80 @@ long pread_parallel(int fd, uint8_t* dst, uint64_t want, uint64_t pos)
     return total;
 }
 
+// ---- multi-line FASTQ ------------------------------------------------------------------------
+//
+// The reference's reader accepts FASTQ records whose sequence and quality are wrapped over several
+// lines (README.md:88, doc/docs/usage.md:357-359): sequence lines run up to the first line that
+// starts with '+', quality lines follow until they hold as many bytes as the sequence.  Where a
+// record ends then depends on every record before it ('@' may start a quality line), so such text
+// cannot be cut into records by a data-parallel scan.  The GPU parser reports it as a format
+// error; the block is then rewritten here, serially, into the four-line form of the same records
+// and parsed again, and so is every later block of the file.  Everything after the parse (kernels,
+// output formatting) is the same path as for four-line files.
+struct FastqNorm {
+    uint64_t nrec = 0;          // complete records rewritten
+    uint64_t consumed = 0;      // bytes of the input they span
+    uint64_t lines = 0;         // input lines they span
+    int64_t error_line = -1;    // 0-based input line of a format violation, or -1
+};
+
+// text[0, n) starts between records.  final: the text ends where the file ends.  The four-line
+// form is appended to `out` (never more than n + 2 bytes per record).
+FastqNorm normalize_fastq(const uint8_t* text, uint64_t n, bool final, std::vector<uint8_t>& out)
+{
+    FastqNorm r;
+    out.clear();
+    uint64_t p = 0, line_no = 0;
+    // next line without its line end; false: no complete line left
+    const uint8_t* lp = nullptr; uint64_t ll = 0;
+    auto next_line = [&]() -> bool {
+        if (p >= n) return false;
+        const uint8_t* nl = static_cast<const uint8_t*>(memchr(text + p, '\n', n - p));
+        uint64_t end;
+        if (nl) end = (uint64_t)(nl - text);
+        else if (final) end = n;
+        else return false;
+        lp = text + p; ll = end - p;
+        while (ll && lp[ll - 1] == '\r') ll--;
+        p = nl ? end + 1 : n;
+        line_no++;
+        return true;
+    };
+    for (;;) {
+        const uint64_t rec_out = out.size();
+        bool got = false;
+        while (next_line()) { if (ll) { got = true; break; } }      // blank lines between records
+        if (!got) {
+            if (p >= n && final) { r.consumed = n; r.lines = line_no; }
+            out.resize(rec_out);
+            return r;
+        }
+        if (lp[0] != '@') { r.error_line = (int64_t)line_no - 1; out.resize(rec_out); return r; }
+        out.insert(out.end(), lp, lp + ll);
+        out.push_back('\n');
+        uint64_t sl = 0, ql = 0;
+        bool plus = false, cut = false;
+        while (true) {
+            if (!next_line()) { cut = !(final && p >= n); break; }
+            if (ll && lp[0] == '+') { plus = true; break; }
+            out.insert(out.end(), lp, lp + ll);
+            sl += ll;
+        }
+        if (cut) { out.resize(rec_out); return r; }
+        out.push_back('\n'); out.push_back('+'); out.push_back('\n');
+        while (ql < sl) {
+            if (!next_line()) { cut = !(final && p >= n); break; }
+            out.insert(out.end(), lp, lp + ll);
+            ql += ll;
+        }
+        if (cut) { out.resize(rec_out); return r; }
+        (void)plus;
+        if (ql != sl) { r.error_line = (int64_t)line_no - 1; out.resize(rec_out); return r; }
+        out.push_back('\n');
+        r.nrec++; r.consumed = p; r.lines = line_no;
+    }
+}
+
 // ---- file text in blocks, parsed on the GPU ------------------------------------------------
 //
 // Reads a file (plain or gzip, "-" = stdin) block by block into the pinned buffer of a text
@@ -161,21 +235,47 @@ public:
                 if (have_ < cap && !eof_) continue;                        // top the block up again
             }
             PhaseTimer pt(1);
-            if (skh_text_parse(ctx_, t_, have_, fastq_ ? SKH_FASTQ : SKH_FASTA, eof_, &res) != SKH_OK) {
-                err_ = skh_last_error();
-                return false;
+            if (!multiline_) {
+                if (skh_text_parse(ctx_, t_, have_, fastq_ ? SKH_FASTQ : SKH_FASTA, eof_, &res) != SKH_OK) {
+                    err_ = skh_last_error();
+                    return false;
+                }
+                if (res.status == SKH_PARSE_EFORMAT && fastq_) multiline_ = true;
+                else if (res.status == SKH_PARSE_EFORMAT) {
+                    err_ = "error when parsing " + path_ + ": invalid FASTA/Q format near line " +
+                           std::to_string(lines_before_ + (uint64_t)res.error_line + 1);
+                    return false;
+                }
             }
-            if (res.status == SKH_PARSE_EFORMAT) {
-                err_ = "error when parsing " + path_ + ": invalid FASTA/Q format near line " +
-                       std::to_string(lines_before_ + (uint64_t)res.error_line + 1) +
-                       (fastq_ ? " (multi-line FASTQ needs --host-parse)" : "");
-                return false;
+            bool no_record = !multiline_ && res.nrec == 0;
+            if (multiline_) {
+                // wrapped FASTQ records: the block's text is kept aside, its four-line form is parsed
+                orig_.assign(buf, buf + have_);
+                const FastqNorm nr = normalize_fastq(orig_.data(), have_, eof_, norm_);
+                if (nr.error_line >= 0) {
+                    err_ = "error when parsing " + path_ + ": invalid FASTA/Q format near line " +
+                           std::to_string(lines_before_ + (uint64_t)nr.error_line + 1);
+                    return false;
+                }
+                no_record = nr.nrec == 0;
+                if (!no_record && norm_.size() <= cap) {
+                    memcpy(buf, norm_.data(), norm_.size());
+                    if (skh_text_parse(ctx_, t_, norm_.size(), SKH_FASTQ, 1, &res) != SKH_OK) { err_ = skh_last_error(); return false; }
+                    if (res.status != SKH_PARSE_OK) { err_ = "error when parsing " + path_ + ": invalid FASTA/Q format"; return false; }
+                    res.consumed = nr.consumed; res.lines = nr.lines;
+                } else if (!no_record) {
+                    no_record = true;                              // the rewritten text needs a larger block
+                    eof_hold_ = true;
+                } else {
+                    memset(&res, 0, sizeof res);
+                }
             }
-            if (res.nrec == 0 && !eof_) {
+            if (no_record && (!eof_ || eof_hold_)) {
                 // not one complete record in a full block: double the block and read on
+                eof_hold_ = false;
                 skh_text* bigger = nullptr;
                 if (skh_text_alloc(ctx_, cap * 2, &bigger) != SKH_OK) { err_ = skh_last_error(); return false; }
-                memcpy(skh_text_buffer(bigger), buf, have_);
+                memcpy(skh_text_buffer(bigger), multiline_ ? orig_.data() : buf, have_);
                 skh_text_free(t_);
                 t_ = bigger;
                 continue;
@@ -193,7 +293,7 @@ public:
     {
         skh_text* bigger = nullptr;
         if (skh_text_alloc(ctx_, skh_text_capacity(t_) * 2, &bigger) != SKH_OK) { err_ = skh_last_error(); return false; }
-        memcpy(skh_text_buffer(bigger), skh_text_buffer(t_), have_);
+        memcpy(skh_text_buffer(bigger), multiline_ ? orig_.data() : skh_text_buffer(t_), have_);
         skh_text_free(t_);
         t_ = bigger;
         consumed_ = 0;
@@ -204,8 +304,9 @@ public:
     void advance(const skh_parse_result& res)
     {
         uint8_t* buf = skh_text_buffer(t_);
-        lines_before_ += fastq_ ? res.nrec * 4 : res.lines;      // for error messages ("near line")
-        memmove(buf, buf + consumed_, have_ - consumed_);
+        lines_before_ += (fastq_ && !multiline_) ? res.nrec * 4 : res.lines;      // for error messages ("near line")
+        if (multiline_) memcpy(buf, orig_.data() + consumed_, have_ - consumed_);  // the buffer holds the rewritten text
+        else memmove(buf, buf + consumed_, have_ - consumed_);
         have_ -= consumed_;
         consumed_ = 0;
     }
@@ -223,6 +324,8 @@ private:
     uint64_t file_size_ = UINT64_MAX, file_pos_ = 0;       // regular plain files only
     uint64_t have_ = 0, consumed_ = 0, lines_before_ = 0;
     bool eof_ = false, done_ = false, format_known_ = false, fastq_ = false, any_ = false;
+    bool multiline_ = false, eof_hold_ = false;            // FASTQ with wrapped records (normalize_fastq)
+    std::vector<uint8_t> orig_, norm_;                     // the block's own text / its four-line form
 };
 
 // ---- the same, as a pipeline -----------------------------------------------------------------
@@ -422,6 +525,8 @@ private:
         Block* acc = nullptr;
         uint64_t acc_off = 0, acc_have = 0;                 // where its text lies
         bool format_known = false;
+        bool multiline = false;                             // FASTQ with wrapped records: blocks are rewritten (normalize_fastq)
+        std::vector<uint8_t> norm;
         uint64_t lines_before = 0;
         for (int k = 1; k < 4 && !s.stop; k++) {
             Block* b = new_block(s, s.block_bytes, false);
@@ -499,33 +604,72 @@ private:
                 continue;
             }
             skh_parse_result res;
-            {
+            if (!multiline) {
                 PhaseTimer pt(1);
                 if (skh_text_parse_at(s.ctx, b->t, off, have, s.fastq ? SKH_FASTQ : SKH_FASTA, eof, &res) != SKH_OK) {
                     s.fail(skh_last_error());
                     break;
                 }
+                if (res.status == SKH_PARSE_EFORMAT && s.fastq) multiline = true;    // the host's copy of the text is intact
             }
-            if (res.status == SKH_PARSE_EFORMAT) {
-                s.fail("error when parsing " + s.path + ": invalid FASTA/Q format near line " +
-                       std::to_string(lines_before + (uint64_t)res.error_line + 1) +
-                       (s.fastq ? " (multi-line FASTQ needs --host-parse)" : ""));
-                break;
-            }
-            if (res.nrec == 0) {
-                if (eof) break;
-                acc = b; acc_off = off; acc_have = have;           // nothing complete yet: more text is needed
-                continue;
+            uint64_t consumed = 0, lines = 0;
+            if (multiline) {
+                const FastqNorm nr = normalize_fastq(buf + off, have, eof, norm);
+                if (nr.error_line >= 0 || (eof && nr.consumed != have)) {
+                    s.fail("error when parsing " + s.path + ": invalid FASTA/Q format near line " +
+                           std::to_string(lines_before + (uint64_t)(nr.error_line >= 0 ? nr.error_line : (int64_t)nr.lines) + 1));
+                    break;
+                }
+                if (nr.nrec == 0) {
+                    if (eof) break;
+                    acc = b; acc_off = off; acc_have = have;       // not one whole record yet: more text is needed
+                    continue;
+                }
+                consumed = nr.consumed; lines = nr.lines;
+            } else {
+                if (res.status == SKH_PARSE_EFORMAT) {
+                    s.fail("error when parsing " + s.path + ": invalid FASTA/Q format near line " +
+                           std::to_string(lines_before + (uint64_t)res.error_line + 1));
+                    break;
+                }
+                if (res.nrec == 0) {
+                    if (eof) break;
+                    acc = b; acc_off = off; acc_have = have;       // nothing complete yet: more text is needed
+                    continue;
+                }
+                consumed = res.consumed; lines = s.fastq ? res.nrec * 4 : res.lines;
             }
             if (!eof) {
                 PhaseTimer pt(6);
-                const uint64_t keep = have - res.consumed;
+                const uint64_t keep = have - consumed;
                 // (capacity doubles: a fresh allocation of this size is paid for in page faults)
                 if (keep > tail.capacity()) { tail.clear(); tail.shrink_to_fit(); tail.reserve(2 * keep); }
                 tail.resize(keep);
-                copy_bytes(tail.data(), buf + off + res.consumed, keep);
+                copy_bytes(tail.data(), buf + off + consumed, keep);
             }
-            lines_before += s.fastq ? res.nrec * 4 : res.lines;
+            if (multiline) {
+                // the four-line form of the block's records takes the place of its text and is parsed
+                if (norm.size() > b->cap) {                        // (records without any sequence line grow by two bytes)
+                    Block* nb = replace_block(s, b, 2 * norm.size());
+                    if (!nb) break;
+                    nb->eof = b->eof;
+                    drop_block(b);
+                    b = nb;
+                    b->head = headroom(*b);
+                }
+                memcpy(skh_text_buffer(b->t), norm.data(), norm.size());
+                PhaseTimer pt(1);
+                if (skh_text_upload(s.ctx, b->t, 0, 0) != SKH_OK ||
+                    skh_text_parse_at(s.ctx, b->t, 0, norm.size(), SKH_FASTQ, 1, &res) != SKH_OK) {
+                    s.fail(skh_last_error());
+                    break;
+                }
+                if (res.status != SKH_PARSE_OK || res.nrec == 0) {
+                    s.fail("error when parsing " + s.path + ": invalid FASTA/Q format");
+                    break;
+                }
+            }
+            lines_before += lines;
             b->res = res;
             s.parsed_q.push(b);
             if (eof) break;

@@ -70,6 +70,11 @@ def length_cases():
                                       rng.integers(1, 400, 300)]),
         "one_5mb": np.array([5 * 1024 * 1024 + 13]),
         "two_long_unaligned": np.array([7, 300007, 11, 299993, 5]),
+        # short reads whose mean length a few records of megabases inflate: the short kernels take their
+        # lanes per record from the sampled short records, the long-record kernels walk the offsets
+        "reads_plus_contigs": np.concatenate([np.full(1500, 150), [2_000_003], np.full(1500, 150), [1_500_000, 151],
+                                              rng.integers(30, 152, 2000), [40000]]),
+        "long_run_of_longs": np.concatenate([rng.integers(33000, 70000, 40), [12], rng.integers(100, 200, 600)]),
     }
 
 
