@@ -117,6 +117,20 @@ int skh_stats_dev(skh_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_offsets,
                   uint64_t nrec, uint64_t total_bytes, const uint8_t is_gap[256],
                   skh_stats_partial *d_out, void *stream);
 
+/* skh_stats_dev for callers that cannot allocate device memory (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc): same arguments, same result, but the kernel's
+ * scratch (512 partial gap sums, 4 KiB) lies in a static array inside the library's device image
+ * instead of memory the library allocated, and nothing on this path allocates or frees.  It has no
+ * counterpart in the reference.  Limits: total_bytes <= SKH_STATS_STATIC_MAX_BYTES and
+ * nrec <= SKH_STATS_STATIC_MAX_RECORDS, else SKH_ECAPACITY.  Every call on a GPU shares that GPU's
+ * one array (cleared by each call on its stream): calls that overlap on one GPU (different streams,
+ * or different contexts on the same device) race and must be serialised by the caller. */
+#define SKH_STATS_STATIC_MAX_BYTES   (1ull << 40)
+#define SKH_STATS_STATIC_MAX_RECORDS (1ull << 36)
+int skh_stats_static_dev(skh_ctx *ctx, const uint8_t *d_seq, const uint64_t *d_offsets,
+                         uint64_t nrec, uint64_t total_bytes, const uint8_t is_gap[256],
+                         skh_stats_partial *d_out, void *stream);
+
 /* Sequence validation: seq.NewSeq's check with seq.ValidateSeq set (bio/seq; settings at
  * seqkit/cmd/seq.go:84-93, reached through the reader at seq.go:115-127).  The first `limit`
  * bytes of every record (all of them when limit == 0) must be members of the alphabet:

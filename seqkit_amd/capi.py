@@ -76,6 +76,7 @@ SYMBOLS = {
     "skh_revcomp_fastq_dev": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_uint64, C.c_uint64, u8p, C.c_int, vp]),
     "skh_count_dev": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_uint64, u8p, C.c_uint32, vp, vp]),
     "skh_stats_dev": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_uint64, u8p, vp, vp]),
+    "skh_stats_static_dev": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_uint64, u8p, vp, vp]),
     "skh_parse_workspace_size": (C.c_uint64, [C.c_uint64, C.c_uint64]),
     "skh_parse_dev": (C.c_int, [vp, vp, C.c_uint64, C.c_int, C.c_int, vp, vp, C.c_uint64, vp, vp, vp, C.c_uint64,
                                 vp, C.c_uint64, C.c_uint64, vp, vp]),

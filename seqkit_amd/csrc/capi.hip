@@ -56,11 +56,18 @@ int env_int(const char* name, int dflt)
 
 }  // namespace
 
+// Scratch of skh_stats_static_dev: the partial gap sums of one launch of the stats kernel, in the
+// library's own image instead of allocated memory.  Every GPU holds its own copy at its own address
+// (skh_init asks for it with hipGetSymbolAddress, with that GPU current); host code uses that
+// address, never this name.
+static __device__ __align__(256) unsigned long long scratch[skh::STATS_SLOT_WORDS];
+
 struct skh_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     skh::BatchHint* d_hints = nullptr;     // N_SLOTS launch hints, one per stream in use
     uint64_t* d_stat_slots = nullptr;      // N_SLOTS scratch areas of the stats kernel (partial gap sums)
+    unsigned long long* d_static_scratch = nullptr;   // this GPU's copy of `scratch`
     std::mutex slot_mu;
     std::unordered_map<hipStream_t, uint32_t> slot_of;
     uint32_t max_grid = 0;
@@ -200,6 +207,8 @@ int skh_init(int device, skh_ctx** out)
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->d_hints), N_SLOTS * sizeof(skh::BatchHint));
     if (e == hipSuccess) e = hipMemset(c->d_hints, 0, N_SLOTS * sizeof(skh::BatchHint));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->d_stat_slots), (size_t)N_SLOTS * skh::STATS_SLOT_WORDS * 8);
+    // this GPU's address of the static scratch array (the device was made current above)
+    if (e == hipSuccess) e = hipGetSymbolAddress(reinterpret_cast<void**>(&c->d_static_scratch), HIP_SYMBOL(scratch));
     if (e != hipSuccess) {
         skh_destroy(c);
         return hip_fail(e, "skh_init");
@@ -420,6 +429,30 @@ int skh_stats_dev(skh_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_offsets,
     uint64_t* slots = ctx->d_stat_slots + (uint64_t)slot * skh::STATS_SLOT_WORDS;
     HIP_TRY(skh::launch_stats(cfg_for(ctx, nrec, total_bytes), d_seq, d_offsets, nrec, total_bytes, t,
                               reinterpret_cast<skh::StatsPartial*>(d_out), slots, st));
+    return SKH_OK;
+}
+
+int skh_stats_static_dev(skh_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_offsets, uint64_t nrec,
+                         uint64_t total_bytes, const uint8_t is_gap[256], skh_stats_partial* d_out, void* stream)
+{
+    // skh_stats_dev with the kernel's partial sums in the static scratch array of this GPU: no
+    // allocation here or on any path below (a memset node and three kernel launches)
+    if (!ctx) return fail(SKH_EINVAL, "ctx is NULL");
+    if (!is_gap || !d_out) return fail(SKH_EINVAL, "NULL argument");
+    if (total_bytes > SKH_STATS_STATIC_MAX_BYTES)
+        return fail(SKH_ECAPACITY, "skh_stats_static_dev: total_bytes exceeds SKH_STATS_STATIC_MAX_BYTES");
+    if (nrec > SKH_STATS_STATIC_MAX_RECORDS)
+        return fail(SKH_ECAPACITY, "skh_stats_static_dev: nrec exceeds SKH_STATS_STATIC_MAX_RECORDS");
+    int rc = check_plane_args(d_seq, d_offsets, nrec, total_bytes);
+    if (rc) return rc;
+    if (!ctx->d_static_scratch) return fail(SKH_EHIP, "skh_stats_static_dev: the static scratch array has no device address");
+    skh::Table256 t;
+    memcpy(t.v, is_gap, 256);
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    HIP_TRY(skh::launch_stats(cfg_for(ctx, nrec, total_bytes), d_seq, d_offsets, nrec, total_bytes, t,
+                              reinterpret_cast<skh::StatsPartial*>(d_out),
+                              reinterpret_cast<uint64_t*>(ctx->d_static_scratch), st));
     return SKH_OK;
 }
 
