@@ -240,7 +240,7 @@ public:
                     err_ = skh_last_error();
                     return false;
                 }
-                if (res.status == SKH_PARSE_EFORMAT && fastq_) multiline_ = true;
+                if (fastq_ && (res.status == SKH_PARSE_EFORMAT || (res.nrec == 0 && (buf[0] == '\n' || buf[0] == '\r')))) multiline_ = true;
                 else if (res.status == SKH_PARSE_EFORMAT) {
                     err_ = "error when parsing " + path_ + ": invalid FASTA/Q format near line " +
                            std::to_string(lines_before_ + (uint64_t)res.error_line + 1);
@@ -610,7 +610,11 @@ private:
                     s.fail(skh_last_error());
                     break;
                 }
-                if (res.status == SKH_PARSE_EFORMAT && s.fastq) multiline = true;    // the host's copy of the text is intact
+                // (the host's copy of the text is intact)  A block that starts with a blank line holds no
+                // four-line record for the GPU parser either: blank lines between records are the serial
+                // scan's business too.
+                if (s.fastq && (res.status == SKH_PARSE_EFORMAT ||
+                                (res.nrec == 0 && (buf[off] == '\n' || buf[off] == '\r')))) multiline = true;
             }
             uint64_t consumed = 0, lines = 0;
             if (multiline) {

@@ -128,3 +128,26 @@ def dev_empty_like_plane(n, device="cuda:0", fill=0xEE):
 
 def ptr(t):
     return C.c_void_p(t.data_ptr())
+
+
+# ---------------------------------------------------------------- text fixtures
+
+def wrapped_fastq(path, width=60, four_line_head=0, crlf=False):
+    """reads_1.fq.gz with sequence and quality wrapped at `width` columns (quality lines then start with
+    '@' and '+' now and then); the first `four_line_head` records stay four-line."""
+    import gzip
+    with gzip.open(os.path.join(GOLDEN, "reads_1.fq.gz"), "rb") as fh:
+        lines = fh.read().split(b"\n")
+    eol = b"\r\n" if crlf else b"\n"
+    out = []
+    for i in range(0, len(lines) - 3, 4):
+        name, seq, qual = lines[i], lines[i + 1], lines[i + 3]
+        w = len(seq) + 1 if i // 4 < four_line_head else width
+        out.append(name)
+        out += [seq[k:k + w] for k in range(0, len(seq), w)] or [b""]
+        out.append(b"+" + (name[1:] if i % 8 == 0 else b""))
+        out += [qual[k:k + w] for k in range(0, len(qual), w)] or [b""]
+        if i % 40 == 0:
+            out.append(b"")                           # blank lines between records
+    with open(path, "wb") as fh:
+        fh.write(eol.join(out) + eol)

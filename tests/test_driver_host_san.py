@@ -1,0 +1,118 @@
+"""The HOST side of the driver (seqkit_amd/host/*.cpp: block pipeline, tail carry, multi-line FASTQ
+rewrite, output ordering) under AddressSanitizer + UBSan and ThreadSanitizer, on the CPU.
+
+tests/stub/ builds the driver's own sources against a CPU restatement of the C ABI (test
+infrastructure that forwards the arithmetic to the oracle; never shipped).  What these tests prove is
+about the host code only: no memory error, no undefined behaviour, no data race, and bytes equal to
+the oracle CLI's.  GPU parity of the same command lines is tests/test_gpu_cli.py's business."""
+import json
+import os
+import subprocess
+
+import pytest
+
+from conftest import GOLDEN, ROOT, check_vector, run_cli
+from helpers import wrapped_fastq
+
+STUB = os.path.join(ROOT, "tests", "stub")
+
+with open(os.path.join(GOLDEN, "expected", "manifest.json")) as _fh:
+    _NAMES = sorted(json.load(_fh))
+
+
+@pytest.fixture(scope="session")
+def san():
+    subprocess.check_call(["make", "-C", STUB, "-s", "-j4"])
+    os.environ["ASAN_OPTIONS"] = "detect_leaks=1:abort_on_error=0:exitcode=99"
+    os.environ["UBSAN_OPTIONS"] = "print_stacktrace=1:halt_on_error=1:exitcode=98"
+    os.environ["TSAN_OPTIONS"] = "halt_on_error=1:exitcode=97:report_signal_unsafe=0"
+    return {"asan": os.path.join(STUB, "seqkit-hip-asan"), "tsan": os.path.join(STUB, "seqkit-hip-tsan")}
+
+
+def clean(result):
+    rc, _, err = result
+    assert rc not in (97, 98, 99) and b"Sanitizer" not in err and b"runtime error" not in err, err.decode("latin-1")[-3000:]
+    return result
+
+
+@pytest.mark.parametrize("name", _NAMES)
+def test_documented_vectors_under_asan(san, name, manifest):
+    check_vector(san["asan"], name, manifest[name])
+
+
+COMMANDS = [["seq", "-r", "-p"], ["seq", "-r", "-p", "-w", "0"], ["seq", "-n", "-i"], ["fx2tab", "-n", "-l", "-g", "-B", "AGCT"],
+            ["fx2tab", "-a"], ["stats", "-a"], ["stats", "-T"], ["subseq", "-r", "2:-2"], ["seq", "-g", "-u"]]
+FILES = ["hairpin.fa.gz", "reads_1.fq.gz", "contigs.fa", "Illimina1.5.fq"]
+
+
+@pytest.mark.parametrize("which", ["asan", "tsan"])
+@pytest.mark.parametrize("argv", COMMANDS, ids=lambda v: " ".join(v))
+def test_commands_small_blocks(san, oracle_cli, argv, which):
+    # blocks of a few records: every block boundary falls inside a record somewhere, tails are carried,
+    # the three pipeline threads hand blocks round all the time
+    for f in FILES:
+        want = run_cli(oracle_cli, argv + [f])
+        for extra in ([], ["--batch-bytes", "4096"], ["--batch-bytes", "30000"]):
+            got = clean(run_cli(san[which], argv + extra + [f]))
+            assert got[0] == want[0] and got[1] == want[1], (f, extra, got[2][-500:])
+
+
+@pytest.mark.parametrize("which", ["asan", "tsan"])
+def test_long_records_and_several_files(san, oracle_cli, which, tmp_path):
+    # records much longer than a block (the block grows, the accumulator path), several files in a row
+    import numpy as np
+    rng = np.random.default_rng(3)
+    big = tmp_path / "big.fa"
+    with open(big, "wb") as fh:
+        for i, n in enumerate([700000, 12, 0, 250000, 90000, 5]):
+            s = rng.choice(np.frombuffer(b"ACGTacgtNn-", np.uint8), size=n).tobytes()
+            fh.write(b">c%d some text\n" % i)
+            for a in range(0, n, 70):
+                fh.write(s[a:a + 70] + b"\n")
+    for argv in (["seq", "-r", "-p"], ["fx2tab", "-n", "-l", "-g"], ["stats", "-a", "-T"]):
+        files = [str(big), "hairpin.fa.gz", str(big)]
+        want = run_cli(oracle_cli, argv + files)
+        got = clean(run_cli(san[which], argv + ["--batch-bytes", "65536"] + files))
+        assert got[0] == want[0] == 0 and got[1] == want[1], argv
+
+
+@pytest.mark.parametrize("which", ["asan", "tsan"])
+def test_multiline_fastq(san, oracle_cli, which, tmp_path):
+    variants = {"wrapped": dict(), "late": dict(four_line_head=1500), "crlf": dict(crlf=True, width=37)}
+    for name, kw in variants.items():
+        f = str(tmp_path / (name + ".fq"))
+        wrapped_fastq(f, **kw)
+        for argv in (["seq", "-r", "-p", "-w", "0"], ["seq"], ["fx2tab", "-n", "-l", "-g", "-B", "AGCT"], ["stats", "-a"],
+                     ["convert", "--to", "Illumina-1.5+"], ["subseq", "-r", "3:-3"]):
+            want = run_cli(oracle_cli, argv + [f])
+            for extra in ([], ["--batch-bytes", "20000"]):
+                got = clean(run_cli(san[which], argv + extra + [f]))
+                assert got[0] == want[0] == 0 and got[1] == want[1], (name, argv, extra, got[2][-500:])
+    with open(f, "rb") as fh:
+        text = fh.read().decode("latin-1")
+    want = run_cli(oracle_cli, ["seq", "-r", "-p"], stdin=text)
+    got = clean(run_cli(san[which], ["seq", "-r", "-p"], stdin=text))
+    assert got[0] == 0 and got[1] == want[1]
+
+
+def test_multiline_fastq_small_cases(san, oracle_cli):
+    cases = ["@r1\nACGT\nAC\n+\nIIII\nII\n", "@r1\nACGT\nAC\n+r1\n@III\n+I\n@r2\nAC\n+\nII", "@e\n+\n@r2\nAC\nGT\n+\nIIII\n",
+             "\n\n@r1\nAC\n\nGT\n+\nII\nII\n\n", "@a\nAC\n+\nII\n\n\n@b\nACG\n+\nIII\n"]
+    for text in cases:
+        for argv in (["seq", "-r", "-p"], ["fx2tab", "-l"], ["stats", "-T"]):
+            want = run_cli(oracle_cli, argv, stdin=text)
+            got = clean(run_cli(san["asan"], argv, stdin=text))
+            assert got[0] == want[0] == 0 and got[1] == want[1], (text, argv, got[2])
+    for text in ("@r1\nACGT\n+\nIII\nII\n", "@r1\nACGT\nAC\n+\nIIII\n", "@r1\nACGT\n+\nIIII\nxx\n"):
+        assert run_cli(oracle_cli, ["seq"], stdin=text)[0] == 255
+        rc, _, err = clean(run_cli(san["asan"], ["seq"], stdin=text))
+        assert rc == 255 and b"[ERRO]" in err
+
+
+@pytest.mark.parametrize("which", ["asan", "tsan"])
+def test_host_parse_mode(san, oracle_cli, which):
+    for argv in (["seq", "-r", "-p"], ["fx2tab", "-n", "-l", "-g", "-B", "AT"], ["stats", "-a"]):
+        for f in ("reads_2.fq.gz", "mature.fa.gz"):
+            want = run_cli(oracle_cli, argv + [f])
+            got = clean(run_cli(san[which], argv + ["--host-parse", "--batch-records", "100"] + [f]))
+            assert got[0] == 0 and got[1] == want[1]

@@ -9,6 +9,7 @@ import os
 import pytest
 
 from conftest import GOLDEN, ROOT, check_vector, run_cli
+from helpers import wrapped_fastq
 
 pytestmark = pytest.mark.gpu
 
@@ -85,13 +86,46 @@ def test_seq_validation(cli, oracle_cli, mode, tmp_path):
     assert want[0] == 255
 
 
-def test_seq_multiline_fastq(cli, oracle_cli):
-    text = "@r1\nACGT\nAC\n+\nIIII\nII\n"
-    rc, _, err = run_cli(cli, ["seq"], stdin=text)
-    assert rc == 255 and b"--host-parse" in err
-    want = run_cli(oracle_cli, ["seq", "-r", "-p"], stdin=text)
-    got = run_cli(cli, ["seq", "--host-parse", "-r", "-p"], stdin=text)
-    assert got[0] == want[0] == 0 and got[1] == want[1]
+MULTILINE_COMMANDS = [["seq"], ["seq", "-r", "-p", "-w", "0"], ["seq", "-r", "-p"], ["seq", "-n", "-i"], ["seq", "-q"],
+                      ["fx2tab", "-n", "-l", "-g", "-B", "AGCT"], ["fx2tab"], ["stats"], ["stats", "-a", "-T"],
+                      ["subseq", "-r", "3:-3"], ["convert", "--to", "Illumina-1.5+"]]
+
+
+@pytest.mark.parametrize("argv", MULTILINE_COMMANDS, ids=lambda v: " ".join(v))
+def test_multiline_fastq_default_path(cli, oracle_cli, argv, tmp_path):
+    # README.md:88, doc/docs/usage.md:357-359 of the reference: multi-line FASTQ is read like any other;
+    # here without any flag, from files and from standard input, whatever the block size
+    variants = {"wrapped": dict(), "late": dict(four_line_head=1500), "crlf": dict(crlf=True, width=37)}
+    for name, kw in variants.items():
+        f = str(tmp_path / (name + ".fq"))
+        wrapped_fastq(f, **kw)
+        want = run_cli(oracle_cli, argv + [f])
+        assert want[0] == 0
+        for extra in ([], ["--batch-bytes", "20000"]):
+            got = run_cli(cli, argv + extra + [f])
+            assert got[0] == 0 and got[1] == want[1], (name, extra, got[2])
+        with open(f, "rb") as fh:
+            text = fh.read().decode("latin-1")
+        got = run_cli(cli, argv, stdin=text)
+        want_stdin = run_cli(oracle_cli, argv, stdin=text)
+        assert got[0] == 0 and got[1] == want_stdin[1], name
+
+
+def test_multiline_fastq_small_cases(cli, oracle_cli):
+    cases = ["@r1\nACGT\nAC\n+\nIIII\nII\n",                       # the documented shape
+             "@r1\nACGT\nAC\n+r1\n@III\n+I\n@r2\nAC\n+\nII",         # quality lines starting with '@' / '+', no final newline
+             "@e\n+\n@r2\nAC\nGT\n+\nIIII\n",                        # a record without any sequence line
+             "\n\n@r1\nAC\n\nGT\n+\nII\nII\n\n"]                     # blank lines inside the sequence
+    for text in cases:
+        for argv in (["seq", "-r", "-p"], ["fx2tab", "-l"], ["stats", "-T"]):
+            want = run_cli(oracle_cli, argv, stdin=text)
+            got = run_cli(cli, argv, stdin=text)
+            assert got[0] == want[0] == 0 and got[1] == want[1], (text, argv, got[2])
+    # quality longer or shorter than the sequence stays an error (exit status 255)
+    for text in ("@r1\nACGT\n+\nIII\nII\n", "@r1\nACGT\nAC\n+\nIIII\n"):
+        assert run_cli(oracle_cli, ["seq"], stdin=text)[0] == 255
+        rc, _, err = run_cli(cli, ["seq"], stdin=text)
+        assert rc == 255 and b"[ERRO]" in err
 
 
 @pytest.mark.parametrize("mode", MODES, ids=["gpu-text", "host-parse"])
