@@ -4,21 +4,30 @@
   python bench.py --gpus N --steps K --warmup W
 
 A step is one pass of the hot path over one resident batch: `seq -r -p` on a FASTQ
-batch (bases reversed + complemented, qualities reversed, one fused launch) followed
-by the `fx2tab -g -B` per-record base counts (classes G, C, A, T) of the same batch.
+batch (bases reversed + complemented, qualities reversed) followed by the `fx2tab -g -B`
+per-record base counts (classes G, C, A, T) of the same batch.
 Workload = BASELINE.json configs[1]: synthetic 10 M x 150 bp Illumina-like FASTQ
 (seed 0xC2 + rank), resident in HBM before the timed region.  With N > 1 every rank
 holds its own batch of that size (records are independent: weak scaling, no
-collective in the data path); the `stats` totals are all-reduced once over RCCL after
-the timed loop and checked.
+collective in the data path).
 
 One JSON line on rank 0: value = bases processed by all ranks per second of the
-slowest rank, plus per-kernel roofline figures from HIP events on the launch stream,
-the CPU oracle timed on a bounded sample and, at N = 1, the end-to-end rate of the
-`seqkit-hip` driver on the same batch written as a FASTQ file (`end_to_end`, never `value`).
+slowest rank, plus
+  roofline / kernels   per-kernel figures from HIP events on the launch stream;
+  configs              the other BASELINE configurations measured in the same run: at N = 1 their
+                       single-GPU kernels (100 M x 150 bp counts, 24 chromosome-length records,
+                       nanopore-like lengths), at N > 1 the same total work cut over the ranks by
+                       byte volume (strong scaling; chromosomes cut inside the records);
+  stats                the path's one collective: per-GPU `stats` totals all-reduced by the
+                       library over RCCL (skh_comm_init_rank + skh_stats_allreduce_dev), timed;
+  cpu_baseline         the CPU oracle on a bounded sample, one thread, and the same over all host
+                       cores (N = 1 only);
+  end_to_end           the `seqkit-hip` driver on the same batch written as a FASTQ file
+                       (N = 1 only; never `value`).
 """
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
 import subprocess
@@ -30,15 +39,33 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak
 
+GRCH38 = [248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345973, 145138636, 138394717,
+          133797422, 135086622, 133275309, 114364328, 107043718, 101991189, 90338345, 83257441, 80373285,
+          58617616, 64444167, 46709983, 50818468, 156040895, 57227415]
+
+
+def kernels_sha16():
+    with open(os.path.join(ROOT, "seqkit_amd", "csrc", "kernels.hip"), "rb") as fh:
+        return hashlib.sha256(fh.read()).hexdigest()[:16]
+
 
 def measured_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/), valid
-    for the default workload only; None otherwise."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as fh:
-            return json.load(fh)["kernels"][kernel]["hbm_bytes"]
-    except (OSError, KeyError, ValueError):
-        return None
+    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC passes (profiles/*_hbm_traffic.json),
+    valid for the default workload and only while kernels.hip is the file the passes were run on (the
+    json carries its hash); None otherwise."""
+    best = None
+    pdir = os.path.join(ROOT, "profiles")
+    for name in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        if not name.endswith("_hbm_traffic.json"):
+            continue
+        try:
+            with open(os.path.join(pdir, name)) as fh:
+                doc = json.load(fh)
+            if doc.get("kernels_sha16") == kernels_sha16():
+                best = doc["kernels"][kernel]["hbm_bytes"]
+        except (OSError, KeyError, ValueError):
+            pass
+    return best
 
 
 def parse():
@@ -48,63 +75,97 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--nrec", type=int, default=10_000_000, help="records per GPU (default: configs[1])")
     ap.add_argument("--read-len", type=int, default=150)
-    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline budget (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline budget per leg (0 = skip)")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the file-to-file run of the driver")
+    ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configurations")
     return ap.parse_args()
 
 
-def synth_fastq(nrec, L, seed, dev):
-    """Illumina-like planes generated on the GPU: bases iid over ACGT with P(N) = 2.5e-5,
-    qualities iid in '#'..'I'."""
+def synth_plane(total, seed, dev, letters=b"ACGT", weights=None, p_n=2.5e-5, with_qual=False):
+    """Bases iid over `letters` (uniform, or `weights`) with P(N) = p_n, qualities iid in '#'..'I',
+    generated on the GPU; planes padded to 16 bytes."""
     import torch
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
-    total = nrec * L
     padded = (total + 15) & ~15
     seq = torch.zeros(padded, dtype=torch.uint8, device=dev)
-    qual = torch.zeros(padded, dtype=torch.uint8, device=dev)
-    letters = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    qual = torch.zeros(padded, dtype=torch.uint8, device=dev) if with_qual else None
+    lt = torch.tensor(list(letters), dtype=torch.uint8, device=dev)
+    w = torch.tensor(weights, device=dev) if weights is not None else None
     step = 1 << 26
     for a in range(0, total, step):
         b = min(total, a + step)
-        idx = torch.randint(0, 4, (b - a,), generator=g, device=dev, dtype=torch.uint8)
-        chunk = letters[idx.to(torch.int64)]
-        n_mask = torch.rand(b - a, generator=g, device=dev) < 2.5e-5
-        chunk[n_mask] = ord("N")
+        if w is None:
+            idx = torch.randint(0, len(letters), (b - a,), generator=g, device=dev, dtype=torch.uint8).to(torch.int64)
+        else:
+            idx = torch.multinomial(w, b - a, replacement=True, generator=g)
+        chunk = lt[idx]
+        if p_n:
+            chunk[torch.rand(b - a, generator=g, device=dev) < p_n] = ord("N")
         seq[a:b] = chunk
-        qual[a:b] = torch.randint(ord("#"), ord("I") + 1, (b - a,), generator=g, device=dev, dtype=torch.uint8)
-        del idx, chunk, n_mask
+        if with_qual:
+            qual[a:b] = torch.randint(ord("#"), ord("I") + 1, (b - a,), generator=g, device=dev, dtype=torch.uint8)
+        del idx, chunk
+    return seq, qual
+
+
+def synth_fastq(nrec, L, seed, dev):
+    import torch
+    seq, qual = synth_plane(nrec * L, seed, dev, with_qual=True)
     offs = torch.arange(nrec + 1, dtype=torch.int64, device=dev) * L
     return seq, qual, offs
 
 
 def cpu_baseline(seconds, L, lut, cls):
-    """The CPU oracle (plain C restatement, one thread) on a bounded sample of the same
-    workload: reverse-complement with quality reversal + the 4-class count."""
+    """The CPU oracle (plain C restatement) on a bounded sample of the same workload: reverse-complement
+    with quality reversal + the 4-class count.  One thread, then the same work over all host cores
+    (threads over record ranges: ctypes releases the GIL around the calls)."""
     import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from helpers import Oracle, make_batch
     so = os.path.join(ROOT, "oracle", "libseqkit_oracle.so")
     if not os.path.exists(so):
-        return None
+        return None, None
     ora = Oracle(C.CDLL(so))
     nrec = 400_000
     seq, qual, offs = make_batch(np.full(nrec, L), seed=0xC2, letters=b"ACGT", with_qual=True)
     lut_np = np.frombuffer(bytes(lut), np.uint8)
     cls_np = np.frombuffer(bytes(cls), np.uint8)
+
+    def one_pass(s, q, o):
+        ora.transform(s, q, o, lut_np, True)
+        ora.count(s, o, cls_np, 4)
+
     done, t0 = 0, time.perf_counter()
     while True:
-        ora.transform(seq, qual, offs, lut_np, True)
-        ora.count(seq, offs, cls_np, 4)
+        one_pass(seq, qual, offs)
         done += 1
         el = time.perf_counter() - t0
         if el >= seconds or done >= 1000:
             break
-    bases = done * nrec * L
-    return {"value": round(bases / el / 1e9, 4), "unit": "Gbases/s", "cores": 1, "kind": "port",
-            "sample": "%d passes over %d x %d bp FASTQ records (%.1f s): oracle reverse-complement + quality "
-                      "reversal + 4-class count, plain C, 1 thread" % (done, nrec, L, el)}
+    single = {"value": round(done * nrec * L / el / 1e9, 4), "unit": "Gbases/s", "cores": 1, "kind": "port",
+              "sample": "%d passes over %d x %d bp FASTQ records (%.1f s): oracle reverse-complement + quality "
+                        "reversal + 4-class count, plain C, 1 thread" % (done, nrec, L, el)}
+    # all cores of this process's share of the host: one copy of the sample per thread
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    env = os.environ.get("OMP_NUM_THREADS")
+    if env and env.isdigit():
+        cores = max(1, min(cores, int(env)))
+    parts = [(seq.copy(), qual.copy(), offs) for _ in range(cores)]
+    with ThreadPoolExecutor(cores) as pool:
+        done, t0 = 0, time.perf_counter()
+        while True:
+            list(pool.map(lambda p: one_pass(*p), parts))
+            done += 1
+            el = time.perf_counter() - t0
+            if el >= seconds or done >= 1000:
+                break
+    multi = {"value": round(done * cores * nrec * L / el / 1e9, 4), "unit": "Gbases/s", "cores": cores, "kind": "port",
+             "sample": "%d rounds of %d threads, each one pass over its own %d x %d bp records (%.1f s): the same oracle "
+                       "work on every core this process may use" % (done, cores, nrec, L, el)}
+    return single, multi
 
 
 def write_fastq_text(path, nrec, L, seq, qual):
@@ -175,6 +236,147 @@ def end_to_end(nrec, L, seq, qual):
         shutil.rmtree(d, ignore_errors=True)
 
 
+class Bench:
+    """The library, one context and one launch stream with HIP-event timing on that stream."""
+
+    def __init__(self, lib, ctx, dev):
+        import torch
+        self.torch, self.lib, self.ctx, self.dev = torch, lib, ctx, dev
+        self.stream = torch.cuda.Stream(device=dev)      # non-null handle: the library launches on exactly this stream
+        assert self.stream.cuda_stream != 0
+        self.sp = C.c_void_p(self.stream.cuda_stream)
+        self.lut = lib.pair_table(1)                     # DNAredundant (reader's guess for ACGTN reads)
+        self.cls = lib.class_table(["G", "C", "A", "T"])  # fx2tab -g -B AGCT needs G, C and A+T
+        self.gap = (C.c_uint8 * 256)()
+        for ch in b"- .":
+            self.gap[ch] = 1
+
+    @staticmethod
+    def p(t):
+        return C.c_void_p(t.data_ptr())
+
+    def revcomp(self, seq, out, offs, nrec, total, lut=True):
+        self.lib.check(self.lib.skh_revcomp_dev(self.ctx, self.p(seq), self.p(out), self.p(offs), nrec, total,
+                                                self.lut if lut else None, 1, self.sp))
+
+    def count(self, seq, offs, nrec, total, counts):
+        self.lib.check(self.lib.skh_count_dev(self.ctx, self.p(seq), self.p(offs), nrec, total, self.cls, 4,
+                                              self.p(counts), self.sp))
+
+    def stats(self, seq, offs, nrec, total, out):
+        self.lib.check(self.lib.skh_stats_dev(self.ctx, self.p(seq), self.p(offs), nrec, total, self.gap, self.p(out), self.sp))
+
+    def time_ms(self, fn, reps=5, warm=2):
+        """Average duration of fn() over `reps` launches, HIP events on the launch stream."""
+        torch = self.torch
+        for _ in range(warm):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(self.stream)
+        for _ in range(reps):
+            fn()
+        e1.record(self.stream)
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+
+def figure(ms, nbytes, bases):
+    gbs = nbytes / (ms * 1e-3) / 1e9
+    return {"ms": round(ms, 4), "gbases_per_s": round(bases / ms / 1e6, 1), "algorithmic_GBps": round(gbs, 1),
+            "frac": round(gbs / HBM_PEAK_GBS, 4)}
+
+
+def offsets_of(lengths, dev):
+    import numpy as np
+    import torch
+    offs = np.zeros(len(lengths) + 1, np.int64)
+    np.cumsum(np.asarray(lengths, np.int64), out=offs[1:])
+    return torch.from_numpy(offs).to(dev), int(offs[-1])
+
+
+def other_configs(b, rank, world):
+    """BASELINE configs[2], [4] and [3] (kernels only).  One rank: the whole configuration on this GPU.
+    Several ranks: the same total work cut by byte volume (seqkit_amd.shard), every rank timing its share;
+    rank 0 reports the slowest share (strong scaling)."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from seqkit_amd import shard
+    dev, out = b.dev, {}
+    soft = (b"ACGTacgtNn-.", [.24, .24, .24, .24, .0075, .0075, .0075, .0075, .004, .004, .001, .001])
+
+    def slowest(ms):
+        if world == 1:
+            return ms
+        t = torch.tensor([ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # configs[2]: 100 M x 150 bp, fx2tab -n -l -g -B AGCT counts; ranks take equal record ranges
+    nrec_all, L = 100_000_000, 150
+    lo, hi = rank * nrec_all // world, (rank + 1) * nrec_all // world     # = split_by_bytes for equal lengths
+    nrec, total = hi - lo, (hi - lo) * L
+    seq, _ = synth_plane(total, 0xC3 + rank, dev)
+    offs = torch.arange(nrec + 1, dtype=torch.int64, device=dev) * L
+    counts = torch.empty(nrec * 4, dtype=torch.int64, device=dev)
+    ms = slowest(b.time_ms(lambda: b.count(seq, offs, nrec, total, counts)))
+    ok = int(counts.view(nrec, 4).sum()) == int((seq[:total] != ord("N")).sum())
+    out["configs[2] count4 100M x 150bp"] = dict(figure(ms, (total + 8 * (nrec + 1) + 32 * nrec) * world, total * world),
+                                                 records_per_rank=nrec, verified=ok,
+                                                 scaling="strong" if world > 1 else "single GPU")
+    del seq, offs, counts
+    torch.cuda.empty_cache()
+
+    # configs[4]: 24 records with the GRCh38 chromosome lengths; ranks take byte-volume shares cut inside the records
+    pieces = shard.plan_pieces(GRCH38, world)[rank]
+    lens = [p[2] - p[1] for p in pieces]
+    offs, total = offsets_of(lens, dev)
+    nrec = len(lens)
+    seq, _ = synth_plane(total, 0xC5 + rank, dev, soft[0], soft[1], p_n=0)
+    outp, back = torch.empty_like(seq), torch.empty_like(seq)
+    counts = torch.empty(nrec * 4, dtype=torch.int64, device=dev)
+    all_total = sum(GRCH38)
+    ms_rev = slowest(b.time_ms(lambda: b.revcomp(seq, outp, offs, nrec, total)))
+    ms_cnt = slowest(b.time_ms(lambda: b.count(seq, offs, nrec, total, counts)))
+    b.revcomp(outp, back, offs, nrec, total)
+    torch.cuda.synchronize()
+    ok = bool(torch.equal(back[:total], seq[:total]))
+    out["configs[4] revcomp 24 chromosomes"] = dict(figure(ms_rev, 2 * all_total + 8 * 24, all_total), verified=ok,
+                                                    pieces_per_rank=nrec, bytes_per_rank=total,
+                                                    scaling="strong (cuts inside records)" if world > 1 else "single GPU")
+    out["configs[4] count4 24 chromosomes"] = dict(figure(ms_cnt, all_total + 40 * 24, all_total), bytes_per_rank=total)
+    del seq, outp, back, counts, offs
+    torch.cuda.empty_cache()
+
+    # configs[3]: nanopore-like lengths (log-normal, 1 kbp - 1 Mbp), stats / revcomp / counts; contiguous
+    # record ranges of equal byte volume
+    rng = np.random.default_rng(0xC4)
+    lens_all = np.clip(np.exp(rng.normal(np.log(8000), 1.1, 700_000)), 1000, 1_000_000).astype(np.int64)
+    offs_all = np.zeros(len(lens_all) + 1, np.uint64)
+    np.cumsum(lens_all.astype(np.uint64), out=offs_all[1:])
+    lo, hi = shard.split_by_bytes(offs_all, world)[rank]
+    lens = lens_all[lo:hi]
+    offs, total = offsets_of(lens, dev)
+    nrec = len(lens)
+    all_total, all_nrec = int(offs_all[-1]), len(lens_all)
+    seq, _ = synth_plane(total, 0xC4 + rank, dev, soft[0], soft[1], p_n=0)
+    outp = torch.empty_like(seq)
+    counts = torch.empty(nrec * 4, dtype=torch.int64, device=dev)
+    st = torch.zeros(5, dtype=torch.int64, device=dev)
+    ms_st = slowest(b.time_ms(lambda: b.stats(seq, offs, nrec, total, st)))
+    ms_rev = slowest(b.time_ms(lambda: b.revcomp(seq, outp, offs, nrec, total)))
+    ms_cnt = slowest(b.time_ms(lambda: b.count(seq, offs, nrec, total, counts)))
+    torch.cuda.synchronize()
+    got = [int(x) for x in st.cpu()]
+    ok = got[:2] == [nrec, total] and got[3:] == [int(lens.min()), int(lens.max())]
+    tag = "configs[3] %%s nanopore-like %.1f Gbases" % (all_total / 1e9)
+    out[tag % "stats"] = dict(figure(ms_st, all_total + 8 * all_nrec, all_total), verified=ok, records_per_rank=nrec,
+                              bytes_per_rank=total, scaling="strong" if world > 1 else "single GPU")
+    out[tag % "revcomp"] = figure(ms_rev, 2 * all_total + 8 * all_nrec, all_total)
+    out[tag % "count4"] = figure(ms_cnt, all_total + 40 * all_nrec, all_total)
+    return out
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -199,32 +401,26 @@ def main():
 
     lib = seqkit_amd.load()          # fails loudly when the HIP library is missing
     ctx = lib.init(local)
+    b = Bench(lib, ctx, dev)
+    p, sp, stream = b.p, b.sp, b.stream
     nrec, L = args.nrec, args.read_len
     total = nrec * L
     seq, qual, offs = synth_fastq(nrec, L, 0xC2 + rank, dev)
     seq_out, qual_out = torch.empty_like(seq), torch.empty_like(qual)
     counts = torch.empty(nrec * 4, dtype=torch.int64, device=dev)
-    lut = lib.pair_table(1)                          # DNAredundant (reader's guess for ACGTN reads)
-    cls = lib.class_table(["G", "C", "A", "T"])      # fx2tab -g -B AGCT needs G, C and A+T
-    # a stream of our own with a non-null handle: the library launches on exactly this
-    # stream and the HIP events below are recorded on it
-    stream = torch.cuda.Stream(device=dev)
     torch.cuda.synchronize()
-    sp = C.c_void_p(stream.cuda_stream)
-    assert stream.cuda_stream != 0
-    p = lambda t: C.c_void_p(t.data_ptr())
 
     # seq -r -p on FASTQ = bases reversed + complemented, qualities reversed.  The library runs
     # the two planes as two launches of the same kernel; they are issued separately here so
     # that each can be timed on its own (skh_revcomp_fastq_dev does exactly these two calls).
     def revcomp_bases():
-        lib.check(lib.skh_revcomp_dev(ctx, p(seq), p(seq_out), p(offs), nrec, total, lut, 1, sp))
+        b.revcomp(seq, seq_out, offs, nrec, total)
 
     def reverse_quals():
-        lib.check(lib.skh_revcomp_dev(ctx, p(qual), p(qual_out), p(offs), nrec, total, None, 1, sp))
+        b.revcomp(qual, qual_out, offs, nrec, total, lut=False)
 
     def count():
-        lib.check(lib.skh_count_dev(ctx, p(seq), p(offs), nrec, total, cls, 4, p(counts), sp))
+        b.count(seq, offs, nrec, total, counts)
 
     def barrier():
         if world > 1:
@@ -254,32 +450,41 @@ def main():
     qual_ms = sum(e[1].elapsed_time(e[2]) for e in ev) / args.steps
     cnt_ms = sum(e[2].elapsed_time(e[3]) for e in ev) / args.steps
 
-    # `stats` totals: per-GPU partial on the device, then the path's one collective
+    # `stats` totals: per-GPU partial on the device, then the path's one collective, done by the
+    # library over RCCL (one rank per process; the id travels over torch.distributed's own channel)
     stats_d = torch.zeros(5, dtype=torch.int64, device=dev)
-    is_gap = (C.c_uint8 * 256)()
-    for ch in b"- .":
-        is_gap[ch] = 1
-    torch.cuda.synchronize()
-    ts = time.perf_counter()
-    lib.check(lib.skh_stats_dev(ctx, p(seq), p(offs), nrec, total, is_gap, p(stats_d), sp))
-    torch.cuda.synchronize()
-    stats_ms = (time.perf_counter() - ts) * 1e3
-    allreduce_us = None
+    stats_ms = b.time_ms(lambda: b.stats(seq, offs, nrec, total, stats_d), reps=10)
+    idbuf = torch.zeros(128, dtype=torch.uint8, device=dev)
+    if rank == 0:
+        raw = (C.c_uint8 * 128)()
+        lib.check(lib.skh_comm_unique_id(raw))
+        idbuf.copy_(torch.tensor(list(raw), dtype=torch.uint8))
     if world > 1:
-        from seqkit_amd import shard
-        torch.cuda.synchronize(); ta = time.perf_counter()
-        tot = shard.allreduce_stats(stats_d)              # the path's only collective (RCCL)
-        torch.cuda.synchronize(); allreduce_us = (time.perf_counter() - ta) * 1e6
-        stats = [int(x) for x in tot.cpu()]
-    else:
-        stats = [int(x) for x in stats_d.cpu()]
-    assert stats[:2] == [nrec * world, total * world] and stats[3:] == [L, L], stats
+        dist.broadcast(idbuf, src=0)
+    raw = (C.c_uint8 * 128)(*[int(x) for x in idbuf.cpu()])
+    comm = C.c_void_p()
+    t_init = time.perf_counter()
+    lib.check(lib.skh_comm_init_rank(ctx, raw, world, rank, C.byref(comm)))
+    comm_init_s = time.perf_counter() - t_init
+    dparts, streams = (C.c_void_p * 1)(stats_d.data_ptr()), (C.c_void_p * 1)(stream.cuda_stream)
+    allreduce_us = []
+    for it in range(4):                                   # the first call sets up RCCL's channels
+        b.stats(seq, offs, nrec, total, stats_d)
+        barrier()
+        ta = time.perf_counter()
+        lib.check(lib.skh_stats_allreduce_dev(comm, dparts, streams))
+        torch.cuda.synchronize()
+        allreduce_us.append((time.perf_counter() - ta) * 1e6)
+    stats = [int(x) for x in stats_d.cpu()]
+    ok_stats = stats[:2] == [nrec * world, total * world] and stats[3:] == [L, L]
+    assert ok_stats, stats
+    lib.skh_comm_destroy(comm)
 
     ok = True
     if not args.no_verify:
         # size-independent checks at full size: revcomp is an involution; counts add up
         back = torch.empty_like(seq)
-        lib.check(lib.skh_revcomp_dev(ctx, p(seq_out), p(back), p(offs), nrec, total, lut, 1, sp))
+        b.revcomp(seq_out, back, offs, nrec, total)
         torch.cuda.synchronize()
         ok = bool(torch.equal(back[:total], seq[:total])) and \
             int(counts.sum()) == int((seq[:total] != ord("N")).sum()) and \
@@ -290,13 +495,22 @@ def main():
         dist.all_reduce(f, op=dist.ReduceOp.MIN)
         ok = bool(f.item())
 
+    configs = None
+    if not args.no_configs:
+        keep = (seq, qual)
+        if world > 1:                                    # every GPU needs the room; the e2e leg (N = 1) needs the batch
+            del seq_out, qual_out, counts
+            torch.cuda.empty_cache()
+        configs = other_configs(b, rank, world)
+        seq, qual = keep
+
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = world * total * args.steps / elapsed / 1e9
         rev_bytes = 2.0 * total + 8.0 * (nrec + 1)          # one plane read + written, offsets read
         cnt_bytes = 1.0 * total + 8.0 * (nrec + 1) + 32.0 * nrec
+        st_bytes = 1.0 * total + 8.0 * (nrec + 1)
         achieved = rev_bytes / (rev_ms * 1e-3) / 1e9
-        gbs = lambda nbytes, ms: round(nbytes / (ms * 1e-3) / 1e9, 1)
         out = {
             "metric": "Gbases/sec revcomp+base-count (kernel & end-to-end), 1-8 MI355X; % HBM peak",
             "value": round(value, 3), "unit": "Gbases/s", "n_gpus": world, "steps": args.steps,
@@ -311,26 +525,28 @@ def main():
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": measured_traffic("skh::k_reverse_staged<true>")
                          if (nrec, L) == (10_000_000, 150) else None,
+                         "traffic_source": "committed rocprofv3 --pmc passes under profiles/ whose kernels.hip hash (%s) "
+                                           "matches this tree; null otherwise" % kernels_sha16(),
                          "algorithmic_bytes_per_launch": rev_bytes,
                          "avg_launch_ms": round(rev_ms, 4)},
             "kernels": {
-                "revcomp_bases": {"ms": round(rev_ms, 4), "gbases_per_s": round(total / rev_ms / 1e6, 1),
-                                  "algorithmic_GBps": gbs(rev_bytes, rev_ms),
-                                  "frac": round(gbs(rev_bytes, rev_ms) / HBM_PEAK_GBS, 4)},
-                "reverse_quals": {"ms": round(qual_ms, 4), "algorithmic_GBps": gbs(rev_bytes, qual_ms),
-                                  "frac": round(gbs(rev_bytes, qual_ms) / HBM_PEAK_GBS, 4)},
-                "seq_r_p_fastq": {"ms": round(rev_ms + qual_ms, 4),
-                                  "gbases_per_s": round(total / (rev_ms + qual_ms) / 1e6, 1),
-                                  "algorithmic_GBps": gbs(2 * rev_bytes, rev_ms + qual_ms)},
-                "count4": {"ms": round(cnt_ms, 4), "gbases_per_s": round(total / cnt_ms / 1e6, 1),
-                           "algorithmic_GBps": round(cnt_bytes / (cnt_ms * 1e-3) / 1e9, 1),
-                           "frac": round(cnt_bytes / (cnt_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
-                "stats": {"ms_wall": round(stats_ms, 4), "allreduce_us": allreduce_us, "totals": stats},
+                "revcomp_bases": figure(rev_ms, rev_bytes, total),
+                "reverse_quals": figure(qual_ms, rev_bytes, total),
+                "seq_r_p_fastq": figure(rev_ms + qual_ms, 2 * rev_bytes, total),
+                "count4": figure(cnt_ms, cnt_bytes, total),
+                "stats": figure(stats_ms, st_bytes, total),
             },
+            "stats": {"totals": stats, "collective": "skh_stats_allreduce_dev: RCCL all-reduce of 5 x int64 (sum x3, min, max) "
+                                                     "inside libseqkit_hip.so, %d rank(s)" % world,
+                      "allreduce_us": [round(x, 1) for x in allreduce_us], "comm_init_s": round(comm_init_s, 3)},
             "verified": ok,
         }
+        if configs is not None:
+            out["configs"] = configs
         if args.cpu_seconds > 0 and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, L, lut, cls)
+            single, multi = cpu_baseline(args.cpu_seconds, L, b.lut, b.cls)
+            out["cpu_baseline"] = single
+            out["cpu_baseline_all_cores"] = multi
         if not args.no_e2e and world == 1:
             torch.cuda.synchronize()
             try:

@@ -15,7 +15,7 @@
  *    the calling thread is available from skh_last_error();
  *  - no function throws, aborts, or calls exit(); nothing is printed;
  *  - tables (complement LUT, class table) are host memory, read during the call;
- *  - one context drives one GPU; use one process (or one context) per GPU;
+ *  - one context drives one GPU; use one process (or one context) per GPU (see "several GPUs");
  *  - the *_dev entry points take DEVICE pointers and enqueue on `stream`
  *    (a hipStream_t passed as void*, NULL = the context's own stream) without
  *    synchronising; the batch entry points are synchronous.
@@ -268,6 +268,9 @@ int skh_parse_dev(skh_ctx *ctx, const uint8_t *d_text, uint64_t text_bytes, int 
  *                                                     at its first white space)
  *     wrapped(sequence) '\n'                         (print_seq)
  *     ["+\n" if plus_line] wrapped(quality) '\n'     (print_qual)
+ * A batch without a quality plane (d_qual == NULL) printed with print_qual gets an empty quality
+ * string: "+" and an empty line, what the command prints for the records of a FASTA file that
+ * follows a FASTQ file (the layout is decided once, seq.go:140-149,258-276).
  * Records shorter than min_len or longer than max_len (when >= 0) are skipped.
  * The caller maps the command's flags (-n -s -q -i, FASTQ forces line_width 0,
  * seq.go:136-138,163-241) onto these fields.  Names are read from the text the batch was
@@ -422,6 +425,45 @@ int skh_text_subseq(skh_ctx *ctx, skh_text *t, const skh_slice *slices, uint64_t
 int skh_text_remove_gaps(skh_ctx *ctx, skh_text *t, const uint8_t is_gap[256]);
 /* skh_stats_dev on the block, merged into *inout. */
 int skh_text_stats(skh_ctx *ctx, skh_text *t, const uint8_t is_gap[256], skh_stats_partial *inout);
+
+/* The context a text block was allocated on (a driver that deals blocks to several GPUs passes it
+ * to the calls on that block; every skh_text_* call checks that block and context belong together). */
+skh_ctx *skh_text_ctx(const skh_text *t);
+
+/* ---- several GPUs ---------------------------------------------------------------------
+ * The reference's only parallel knob on this path is -j / seq.ComplementThreads
+ * (seqkit/cmd/seq.go:88, root.go:60-64) and its per-file accumulators (stat.go:106-125); here records
+ * are dealt to GPUs instead.  One context per GPU.  Reverse-complement and per-record counts of
+ * different records never meet, so sharding needs no exchange:
+ *   skh_split_by_bytes  cuts[0..nparts]: contiguous record ranges [cuts[k], cuts[k+1]) of about equal
+ *                       byte volume (nearest record boundary to every k/nparts of the bytes);
+ *   skh_split_record    cuts[0..nparts]: byte positions (multiples of 16, then `length`) that cut one
+ *                       long record into slices; input slice [cuts[k], cuts[k+1]) is a record of its
+ *                       own whose reverse(-complement) belongs at [length - cuts[k+1], length - cuts[k])
+ *                       of the result.
+ * The one collective is the merge of the per-GPU `stats` totals, done by RCCL over xGMI:
+ * sum of num / len_sum / gap_sum, min of len_min, max of len_max (skh_stats_merge, element-wise).
+ * A communicator is made either over several contexts of ONE process (skh_comm_init_all: the
+ * driver's --gpus N; contexts that share a device are merged on the host first) or as one rank of a
+ * multi-process job, one GPU per process (rank 0 calls skh_comm_unique_id, hands the bytes to the
+ * other ranks by any means it has, every rank calls skh_comm_init_rank).  RCCL is loaded on first use. */
+typedef struct skh_comm skh_comm;
+#define SKH_COMM_ID_BYTES 128
+int skh_split_by_bytes(const uint64_t *offsets, uint64_t nrec, int nparts, uint64_t *cuts);
+int skh_split_record(uint64_t length, int nparts, uint64_t *cuts);
+int skh_comm_init_all(skh_ctx *const *ctxs, int n, skh_comm **out);
+int skh_comm_unique_id(uint8_t id[SKH_COMM_ID_BYTES]);
+int skh_comm_init_rank(skh_ctx *ctx, const uint8_t id[SKH_COMM_ID_BYTES], int nranks, int rank,
+                       skh_comm **out);
+void skh_comm_destroy(skh_comm *c);
+/* GPUs of this process in the communicator (distinct devices of skh_comm_init_all; 1 for init_rank). */
+int skh_comm_local_ranks(const skh_comm *c);
+/* Host form: partials[i] belongs to context i of skh_comm_init_all (one entry for init_rank); on
+ * return every entry holds the totals over all GPUs and processes.  Synchronous. */
+int skh_stats_allreduce(skh_comm *c, skh_stats_partial *partials);
+/* Device form: d_partials[r] is DEVICE memory on local GPU r (e.g. what skh_stats_dev wrote),
+ * reduced in place on streams[r] (NULL array or entry: the communicator's own stream), not synchronised. */
+int skh_stats_allreduce_dev(skh_comm *c, skh_stats_partial *const *d_partials, void *const *streams);
 
 /* ---- pinned-host batches (what a cgo / C++ reader fills) ---------------------------- */
 

@@ -182,7 +182,7 @@ int main(int argc, char **argv)
            : is_fx  ? ora_cmd_fx2tab(&fo, nfiles, files, out, stderr)
            : is_sub ? ora_cmd_subseq(&uo, nfiles, files, out, stderr)
            : is_cv  ? ora_cmd_convert(&co, nfiles, files, out, stderr)
-                    : ora_cmd_stats(&to, nfiles, files, out, stderr);
+                    : (to.alphabet_plus1 = so.alphabet + 1, ora_cmd_stats(&to, nfiles, files, out, stderr));
     if (out != stdout) fclose(out); else fflush(out);
     return rc;
 }

@@ -633,7 +633,7 @@ int ora_cmd_stats(const ora_stats_opts *o, int nfiles, const char **files, FILE 
         if ((uint8_t)*p > 127) { fprintf(err, "[ERRO] value of -G (--gap-letters) contains non-ASCII characters\n"); return 255; }
     stat_info *infos = (stat_info *)calloc((size_t)nfiles, sizeof *infos);
     for (int f = 0; f < nfiles; f++) {
-        ora_reader *r = ora_reader_open(files[f], -1, o->guess_len);
+        ora_reader *r = ora_reader_open(files[f], o->alphabet_plus1 - 1, o->guess_len);      /* stat.go:87 */
         if (!r) { fprintf(err, "[ERRO] open %s: no such file or directory\n", files[f]); free(infos); return 255; }
         stat_info *s = &infos[f];
         s->file = files[f]; s->format = ""; s->len_min = INT64_MAX;

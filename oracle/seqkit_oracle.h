@@ -153,6 +153,7 @@ typedef struct ora_stats_opts {
     int all, tabular;           /* -a -T */
     const char *gap_letters;    /* -G (default "- .") */
     size_t guess_len;
+    int alphabet_plus1;         /* -t: alphabet id + 1 handed to the reader (stat.go:87), 0 = guess */
 } ora_stats_opts;
 int ora_cmd_stats(const ora_stats_opts *o, int nfiles, const char **files, FILE *out, FILE *err);
 

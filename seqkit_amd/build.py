@@ -10,8 +10,8 @@ ROOT = os.path.dirname(PKG)
 LIB = os.path.join(PKG, "libseqkit_hip.so")
 CLI = os.path.join(PKG, "seqkit-hip")
 
-LIB_SRCS = [os.path.join(PKG, "csrc", f) for f in ("capi.hip", "kernels.hip", "parse.hip", "format.hip", "slices.hip", "gaps.hip")]
-LIB_DEPS = LIB_SRCS + [os.path.join(PKG, "csrc", "kernels.h"), os.path.join(PKG, "csrc", "device_util.h"), os.path.join(ROOT, "include", "seqkit_hip.h")]
+LIB_SRCS = [os.path.join(PKG, "csrc", f) for f in ("capi.hip", "kernels.hip", "parse.hip", "format.hip", "slices.hip", "gaps.hip", "multi.hip")]
+LIB_DEPS = LIB_SRCS + [os.path.join(PKG, "csrc", "kernels.h"), os.path.join(PKG, "csrc", "device_util.h"), os.path.join(PKG, "csrc", "ctx.h"), os.path.join(ROOT, "include", "seqkit_hip.h")]
 CLI_SRCS = [os.path.join(PKG, "host", f) for f in ("main.cpp", "fastx_reader.cpp", "commands.cpp", "format.cpp")]
 CLI_DEPS = CLI_SRCS + [os.path.join(PKG, "host", "host.h"), os.path.join(ROOT, "include", "seqkit_hip.h")]
 
@@ -32,7 +32,7 @@ def build_lib(force=False, verbose=False):
         return LIB
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-I", os.path.join(ROOT, "include"), "-I", os.path.join(PKG, "csrc"),
-           "-Wall", "-Wno-unused-function", "-o", LIB] + LIB_SRCS
+           "-Wall", "-Wno-unused-function", "-o", LIB] + LIB_SRCS + ["-ldl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -123,6 +123,16 @@ SYMBOLS = {
     "skh_letters_dev": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_uint64, vp, vp]),
     "skh_text_letters": (C.c_int, [vp, vp]),
     "skh_text_stats": (C.c_int, [vp, vp, u8p, C.POINTER(StatsPartial)]),
+    "skh_text_ctx": (vp, [vp]),
+    "skh_split_by_bytes": (C.c_int, [u64p, C.c_uint64, C.c_int, u64p]),
+    "skh_split_record": (C.c_int, [C.c_uint64, C.c_int, u64p]),
+    "skh_comm_init_all": (C.c_int, [C.POINTER(vp), C.c_int, C.POINTER(vp)]),
+    "skh_comm_unique_id": (C.c_int, [u8p]),
+    "skh_comm_init_rank": (C.c_int, [vp, u8p, C.c_int, C.c_int, C.POINTER(vp)]),
+    "skh_comm_destroy": (None, [vp]),
+    "skh_comm_local_ranks": (C.c_int, [vp]),
+    "skh_stats_allreduce": (C.c_int, [vp, C.POINTER(StatsPartial)]),
+    "skh_stats_allreduce_dev": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp)]),
     "skh_batch_alloc": (C.c_int, [vp, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(vp)]),
     "skh_batch_free": (None, [vp]),
     "skh_batch_seq": (vp, [vp]),

@@ -18,6 +18,7 @@
 #include <string>
 
 #include "kernels.h"
+#include "ctx.h"
 
 namespace {
 
@@ -62,25 +63,7 @@ int env_int(const char* name, int dflt)
 // address, never this name.
 static __device__ __align__(256) unsigned long long scratch[skh::STATS_SLOT_WORDS];
 
-struct skh_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    skh::BatchHint* d_hints = nullptr;     // N_SLOTS launch hints, one per stream in use
-    uint64_t* d_stat_slots = nullptr;      // N_SLOTS scratch areas of the stats kernel (partial gap sums)
-    unsigned long long* d_static_scratch = nullptr;   // this GPU's copy of `scratch`
-    std::mutex slot_mu;
-    std::unordered_map<hipStream_t, uint32_t> slot_of;
-    uint32_t max_grid = 0;
-    uint32_t n_cu = 256;
-    int force_logG = -1;
-    int span_u = -1;         // -1 = chosen per call from the mean record length
-    int fuse_fastq = 0;
-    int use_hint = 1;
-    int staged = 1;
-    uint32_t staged_steps = 0;
-    uint32_t count_steps = 0;
-    uint32_t stats_steps = 0;
-};
+int skh::set_error(int code, const char* fmt, const char* a, const char* b) { return fail(code, fmt, a, b); }
 
 struct skh_batch {
     skh_ctx* ctx = nullptr;
@@ -598,7 +581,6 @@ static int format_seq_impl(skh_ctx* ctx, const uint64_t* d_filter_offsets, const
     if (fmt->print_name && nrec != 0 && (!d_text || !d_name_pos || !d_name_len))
         return fail(SKH_EINVAL, "names requested without name spans");
     if (fmt->print_seq && nrec != 0 && !d_seq) return fail(SKH_EINVAL, "sequence requested without a sequence plane");
-    if (fmt->print_qual && nrec != 0 && !d_qual) return fail(SKH_EINVAL, "quality requested without a quality plane");
     if (fmt->line_width < 0) return fail(SKH_EINVAL, "line_width is negative");
     if (reinterpret_cast<uintptr_t>(d_workspace) & 255) return fail(SKH_EINVAL, "workspace is not 256-byte aligned");
     if (workspace_bytes < skh::format_workspace_size(nrec))
@@ -1029,6 +1011,7 @@ void skh_text_free(skh_text* t)
 }
 
 uint8_t* skh_text_buffer(skh_text* t) { return t ? t->h_text : nullptr; }
+skh_ctx* skh_text_ctx(const skh_text* t) { return t ? t->ctx : nullptr; }
 uint64_t skh_text_capacity(const skh_text* t) { return t ? t->cap : 0; }
 
 int skh_text_parse(skh_ctx* ctx, skh_text* t, uint64_t text_bytes, int format, int final, skh_parse_result* out)
@@ -1040,6 +1023,7 @@ int skh_text_parse_at(skh_ctx* ctx, skh_text* t, uint64_t text_offset, uint64_t 
                       skh_parse_result* out)
 {
     if (!ctx || !t || !out) return fail(SKH_EINVAL, "NULL argument");
+    if (t->ctx != ctx) return fail(SKH_EINVAL, "the text block belongs to another context");
     if (text_offset > t->cap || text_bytes > t->cap - text_offset) return fail(SKH_ECAPACITY, "text block larger than its buffer");
     HIP_TRY(hipSetDevice(ctx->device));
     // the text goes to the start of the device buffer wherever it starts on the host; the bytes of the
@@ -1090,6 +1074,7 @@ int skh_text_parse_at(skh_ctx* ctx, skh_text* t, uint64_t text_offset, uint64_t 
 int skh_text_upload(skh_ctx* ctx, skh_text* t, uint64_t offset, uint64_t nbytes)
 {
     if (!ctx || !t) return fail(SKH_EINVAL, "NULL argument");
+    if (t->ctx != ctx) return fail(SKH_EINVAL, "the text block belongs to another context");
     if (offset > t->cap || nbytes > t->cap - offset) return fail(SKH_ECAPACITY, "range beyond the block's buffer");
     HIP_TRY(hipSetDevice(ctx->device));
     t->up_bytes = 0;
@@ -1104,6 +1089,7 @@ int skh_text_upload(skh_ctx* ctx, skh_text* t, uint64_t offset, uint64_t nbytes)
 int skh_text_offsets(skh_ctx* ctx, skh_text* t, uint64_t first, uint64_t count, uint64_t* offsets)
 {
     if (!ctx || !t || !offsets) return fail(SKH_EINVAL, "NULL argument");
+    if (t->ctx != ctx) return fail(SKH_EINVAL, "the text block belongs to another context");
     if (first + count > t->nrec + 1) return fail(SKH_EINVAL, "offset range beyond the block's records");
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipMemcpyAsync(offsets, t->v_offs + first, count * 8, hipMemcpyDeviceToHost, t->stream));
@@ -1114,6 +1100,7 @@ int skh_text_offsets(skh_ctx* ctx, skh_text* t, uint64_t first, uint64_t count, 
 int skh_text_sequence(skh_ctx* ctx, skh_text* t, uint64_t first_byte, uint64_t count, uint8_t* dst)
 {
     if (!ctx || !t || (!dst && count)) return fail(SKH_EINVAL, "NULL argument");
+    if (t->ctx != ctx) return fail(SKH_EINVAL, "the text block belongs to another context");
     if (first_byte + count > t->seq_bytes) return fail(SKH_EINVAL, "byte range beyond the block's sequence");
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipMemcpyAsync(dst, (t->transformed ? t->d_seq2 : t->d_seq) + first_byte, count, hipMemcpyDeviceToHost, t->stream));
@@ -1124,6 +1111,7 @@ int skh_text_sequence(skh_ctx* ctx, skh_text* t, uint64_t first_byte, uint64_t c
 int skh_text_revcomp(skh_ctx* ctx, skh_text* t, const uint8_t* lut, int do_reverse, int reverse_qual)
 {
     if (!ctx || !t) return fail(SKH_EINVAL, "NULL argument");
+    if (t->ctx != ctx) return fail(SKH_EINVAL, "the text block belongs to another context");
     if (t->transformed) return fail(SKH_EINVAL, "block was already transformed");
     if (t->nrec == 0 || (!lut && !do_reverse)) return SKH_OK;
     int rc = skh_revcomp_dev(ctx, t->d_seq, t->d_seq2, t->v_offs, t->nrec, t->seq_bytes, lut, do_reverse, t->stream);
@@ -1142,6 +1130,7 @@ int skh_text_revcomp(skh_ctx* ctx, skh_text* t, const uint8_t* lut, int do_rever
 int skh_text_output_wait(skh_ctx* ctx, skh_text* t, const uint8_t** out, uint64_t* out_bytes)
 {
     if (!ctx || !t || !out || !out_bytes) return fail(SKH_EINVAL, "NULL argument");
+    if (t->ctx != ctx) return fail(SKH_EINVAL, "the text block belongs to another context");
     *out = nullptr; *out_bytes = 0;
     if (t->out_pending == 0) return SKH_OK;
     HIP_TRY(hipSetDevice(ctx->device));
@@ -1169,12 +1158,12 @@ int skh_text_format_tab(skh_ctx* ctx, skh_text* t, const skh_tab_format* fmt, co
 int skh_text_format_seq_submit(skh_ctx* ctx, skh_text* t, const skh_seq_format* fmt)
 {
     if (!ctx || !t || !fmt) return fail(SKH_EINVAL, "NULL argument");
+    if (t->ctx != ctx) return fail(SKH_EINVAL, "the text block belongs to another context");
     t->out_pending = 0;
     if (t->nrec == 0) return SKH_OK;
     HIP_TRY(hipSetDevice(ctx->device));
     const uint8_t* seq = t->transformed ? t->d_seq2 : t->d_seq;
     const uint8_t* qual = t->fastq ? (t->transformed ? t->d_qual2 : t->d_qual) : nullptr;
-    if (fmt->print_qual && !qual) return fail(SKH_EINVAL, "quality requested for a FASTA block");
     for (;;) {
         int rc = format_seq_impl(ctx, t->filter_offs, t->v_text, t->v_npos, t->v_nlen, seq, qual, t->v_offs, t->nrec, fmt, t->d_out,
                                  t->out_cap, t->d_fws, t->fws_bytes, static_cast<skh_format_result*>(t->d_res),
@@ -1196,6 +1185,7 @@ int skh_text_format_seq_submit(skh_ctx* ctx, skh_text* t, const skh_seq_format* 
 int skh_text_count(skh_ctx* ctx, skh_text* t, const uint8_t class_of[256], uint32_t nclass, uint32_t pass)
 {
     if (!ctx || !t || !class_of) return fail(SKH_EINVAL, "NULL argument");
+    if (t->ctx != ctx) return fail(SKH_EINVAL, "the text block belongs to another context");
     if (pass >= SKH_TAB_MAX_PASSES) return fail(SKH_EINVAL, "pass out of range");
     if (nclass < 1 || nclass > SKH_MAX_CLASSES) return fail(SKH_EINVAL, "nclass out of range");
     HIP_TRY(hipSetDevice(ctx->device));
@@ -1215,6 +1205,7 @@ int skh_text_count(skh_ctx* ctx, skh_text* t, const uint8_t class_of[256], uint3
 int skh_text_format_tab_submit(skh_ctx* ctx, skh_text* t, const skh_tab_format* fmt)
 {
     if (!ctx || !t || !fmt) return fail(SKH_EINVAL, "NULL argument");
+    if (t->ctx != ctx) return fail(SKH_EINVAL, "the text block belongs to another context");
     t->out_pending = 0;
     if (t->nrec == 0) return SKH_OK;
     HIP_TRY(hipSetDevice(ctx->device));
@@ -1249,6 +1240,7 @@ int skh_text_format_tab_submit(skh_ctx* ctx, skh_text* t, const skh_tab_format* 
 int skh_text_validate(skh_ctx* ctx, skh_text* t, const uint8_t valid[256], uint64_t limit, skh_validate_result* out)
 {
     if (!ctx || !t || !valid || !out) return fail(SKH_EINVAL, "NULL argument");
+    if (t->ctx != ctx) return fail(SKH_EINVAL, "the text block belongs to another context");
     memset(out, 0, sizeof *out);
     if (t->nrec == 0) return SKH_OK;
     HIP_TRY(hipSetDevice(ctx->device));
@@ -1264,6 +1256,7 @@ int skh_text_validate(skh_ctx* ctx, skh_text* t, const uint8_t valid[256], uint6
 int skh_text_truncate(skh_ctx* ctx, skh_text* t, uint64_t nrec)
 {
     if (!ctx || !t) return fail(SKH_EINVAL, "NULL argument");
+    if (t->ctx != ctx) return fail(SKH_EINVAL, "the text block belongs to another context");
     if (nrec > t->nrec) return fail(SKH_EINVAL, "cannot truncate to more records than the block holds");
     if (nrec == t->nrec) return SKH_OK;
     HIP_TRY(hipSetDevice(ctx->device));
@@ -1277,6 +1270,7 @@ int skh_text_truncate(skh_ctx* ctx, skh_text* t, uint64_t nrec)
 int skh_text_name(skh_ctx* ctx, skh_text* t, uint64_t record, uint64_t* pos, uint32_t* len)
 {
     if (!ctx || !t || !pos || !len) return fail(SKH_EINVAL, "NULL argument");
+    if (t->ctx != ctx) return fail(SKH_EINVAL, "the text block belongs to another context");
     if (record >= t->nrec) return fail(SKH_EINVAL, "record beyond the block");
     HIP_TRY(hipSetDevice(ctx->device));
     uint8_t* h = static_cast<uint8_t*>(t->h_res);
@@ -1292,6 +1286,7 @@ int skh_text_name(skh_ctx* ctx, skh_text* t, uint64_t record, uint64_t* pos, uin
 int skh_text_quality(skh_ctx* ctx, skh_text* t, uint64_t first_byte, uint64_t count, uint8_t* dst)
 {
     if (!ctx || !t || (!dst && count)) return fail(SKH_EINVAL, "NULL argument");
+    if (t->ctx != ctx) return fail(SKH_EINVAL, "the text block belongs to another context");
     if (!t->fastq) return fail(SKH_EINVAL, "a FASTA block has no qualities");
     if (first_byte + count > t->seq_bytes) return fail(SKH_EINVAL, "byte range beyond the block's qualities");
     HIP_TRY(hipSetDevice(ctx->device));
@@ -1303,6 +1298,7 @@ int skh_text_quality(skh_ctx* ctx, skh_text* t, uint64_t first_byte, uint64_t co
 int skh_text_validate_quality(skh_ctx* ctx, skh_text* t, const uint8_t valid[256], skh_validate_result* out)
 {
     if (!ctx || !t || !valid || !out) return fail(SKH_EINVAL, "NULL argument");
+    if (t->ctx != ctx) return fail(SKH_EINVAL, "the text block belongs to another context");
     memset(out, 0, sizeof *out);
     if (!t->fastq) return fail(SKH_EINVAL, "a FASTA block has no qualities");
     if (t->nrec == 0) return SKH_OK;
@@ -1319,6 +1315,7 @@ int skh_text_validate_quality(skh_ctx* ctx, skh_text* t, const uint8_t valid[256
 int skh_text_map_quality(skh_ctx* ctx, skh_text* t, const uint8_t lut[256])
 {
     if (!ctx || !t || !lut) return fail(SKH_EINVAL, "NULL argument");
+    if (t->ctx != ctx) return fail(SKH_EINVAL, "the text block belongs to another context");
     if (!t->fastq) return fail(SKH_EINVAL, "a FASTA block has no qualities");
     if (t->transformed) return fail(SKH_EINVAL, "block was already transformed");
     if (t->nrec == 0) return SKH_OK;
@@ -1333,6 +1330,7 @@ int skh_text_map_quality(skh_ctx* ctx, skh_text* t, const uint8_t lut[256])
 int skh_text_names(skh_ctx* ctx, skh_text* t, uint64_t first, uint64_t count, uint64_t* pos, uint32_t* len)
 {
     if (!ctx || !t || ((!pos || !len) && count)) return fail(SKH_EINVAL, "NULL argument");
+    if (t->ctx != ctx) return fail(SKH_EINVAL, "the text block belongs to another context");
     if (first + count > t->nrec) return fail(SKH_EINVAL, "record range beyond the block");
     if (count == 0) return SKH_OK;
     HIP_TRY(hipSetDevice(ctx->device));
@@ -1349,7 +1347,10 @@ int skh_text_subseq(skh_ctx* ctx, skh_text* t, const skh_slice* slices, uint64_t
                     const uint32_t* name_len)
 {
     if (!ctx || !t) return fail(SKH_EINVAL, "NULL argument");
+    if (t->ctx != ctx) return fail(SKH_EINVAL, "the text block belongs to another context");
     if (t->transformed) return fail(SKH_EINVAL, "block was already transformed");
+    if (t->v_offs != t->d_offs)
+        return fail(SKH_EINVAL, "gaps were removed from this block: cut subsequences before skh_text_remove_gaps");
     if (!slices) n = t->nrec;
     if (!names && slices) return fail(SKH_EINVAL, "a slice list needs names for its records");
     if (names && (!name_pos || !name_len)) return fail(SKH_EINVAL, "NULL name table");
@@ -1418,6 +1419,7 @@ int skh_text_subseq(skh_ctx* ctx, skh_text* t, const skh_slice* slices, uint64_t
 int skh_text_letters(skh_ctx* ctx, skh_text* t)
 {
     if (!ctx || !t) return fail(SKH_EINVAL, "NULL argument");
+    if (t->ctx != ctx) return fail(SKH_EINVAL, "the text block belongs to another context");
     HIP_TRY(hipSetDevice(ctx->device));
     const uint64_t need = (t->nrec ? t->nrec : 1) * 8;
     if (need > t->letters_cap) {
@@ -1433,6 +1435,7 @@ int skh_text_letters(skh_ctx* ctx, skh_text* t)
 int skh_text_remove_gaps(skh_ctx* ctx, skh_text* t, const uint8_t is_gap[256])
 {
     if (!ctx || !t || !is_gap) return fail(SKH_EINVAL, "NULL argument");
+    if (t->ctx != ctx) return fail(SKH_EINVAL, "the text block belongs to another context");
     if (t->transformed) return fail(SKH_EINVAL, "block was already transformed");
     if (t->v_offs != t->d_offs) return fail(SKH_EINVAL, "gaps were already removed from this block");
     if (t->nrec == 0) return SKH_OK;
@@ -1470,6 +1473,7 @@ int skh_text_remove_gaps(skh_ctx* ctx, skh_text* t, const uint8_t is_gap[256])
 int skh_text_stats(skh_ctx* ctx, skh_text* t, const uint8_t is_gap[256], skh_stats_partial* inout)
 {
     if (!ctx || !t || !is_gap || !inout) return fail(SKH_EINVAL, "NULL argument");
+    if (t->ctx != ctx) return fail(SKH_EINVAL, "the text block belongs to another context");
     if (t->nrec == 0) return SKH_OK;
     HIP_TRY(hipSetDevice(ctx->device));
     int rc = skh_stats_dev(ctx, t->transformed ? t->d_seq2 : t->d_seq, t->v_offs, t->nrec, t->seq_bytes, is_gap,

@@ -1,0 +1,34 @@
+// ctx.h -- the context object behind skh_ctx*, shared by the host-side sources of the library.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <mutex>
+#include <unordered_map>
+
+#include "kernels.h"
+
+struct skh_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    skh::BatchHint* d_hints = nullptr;     // N_SLOTS launch hints, one per stream in use
+    uint64_t* d_stat_slots = nullptr;      // N_SLOTS scratch areas of the stats kernel (partial gap sums)
+    unsigned long long* d_static_scratch = nullptr;   // this GPU's copy of `scratch`
+    std::mutex slot_mu;
+    std::unordered_map<hipStream_t, uint32_t> slot_of;
+    uint32_t max_grid = 0;
+    uint32_t n_cu = 256;
+    int force_logG = -1;
+    int span_u = -1;         // -1 = chosen per call from the mean record length
+    int fuse_fastq = 0;
+    int use_hint = 1;
+    int staged = 1;
+    uint32_t staged_steps = 0;
+    uint32_t count_steps = 0;
+    uint32_t stats_steps = 0;
+};
+
+namespace skh {
+// sets the calling thread's skh_last_error() text and returns `code` (defined in capi.hip)
+int set_error(int code, const char* fmt, const char* a = "", const char* b = "");
+}

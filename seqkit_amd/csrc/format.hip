@@ -54,7 +54,8 @@ __global__ __launch_bounds__(FB) void k_fmt_sizes(const FormatSeqArgs a, uint64_
                 sz += (a.print_seq ? 1 : 0) + (uint64_t)nl + 1;
             }
             if (a.print_seq) sz += wrapped_len(len, a.width) + 1;
-            if (a.print_qual && !(a.empty_fasta && len == 0)) sz += (a.plus_line ? 2 : 0) + wrapped_len(len, a.width) + 1;
+            // (no quality plane: an empty quality string, as for a FASTA record printed in FASTQ layout)
+            if (a.print_qual && !(a.empty_fasta && len == 0)) sz += (a.plus_line ? 2 : 0) + wrapped_len(a.qual ? len : 0, a.width) + 1;
         }
         size[r] = sz;
         shown_name[r] = nl;
@@ -192,8 +193,9 @@ __global__ __launch_bounds__(FB) void k_fmt_write(const FormatSeqArgs a, const u
         }
         if (a.print_qual && !(a.empty_fasta && len == 0)) {
             if (a.plus_line) { if (j == 0) { o[0] = '+'; o[1] = '\n'; } o += 2; }
-            if (!is_long) copy_wrapped<G>(o, a.qual + s, len, a.width, j);
-            const uint64_t w = wrapped_len(len, a.width);
+            const uint64_t ql = a.qual ? len : 0;
+            if (!is_long && ql) copy_wrapped<G>(o, a.qual + s, ql, a.width, j);
+            const uint64_t w = wrapped_len(ql, a.width);
             if (j == 0) o[w] = '\n';
         }
     }
@@ -254,7 +256,7 @@ __global__ __launch_bounds__(FB) void k_fmt_write_long(const FormatSeqArgs a, co
                 copy_wrapped_range(o, a.seq + s, len, a.width, k0, k1);
                 o += wrapped_len(len, a.width) + 1;
             }
-            if (a.print_qual) {
+            if (a.print_qual && a.qual) {
                 if (a.plus_line) o += 2;
                 copy_wrapped_range(o, a.qual + s, len, a.width, k0, k1);
             }

@@ -33,9 +33,28 @@ void drop_cached_blocks();          // text blocks kept between the files of a c
 
 namespace {
 
+// The contexts of a command: one per entry of --devices / --gpus (c = the first, which also serves
+// everything that is not dealt out: --host-parse batches, the guess pass of convert).
 struct Ctx {
     skh_ctx* c = nullptr;
-    ~Ctx() { drop_cached_blocks(); if (c) skh_destroy(c); }
+    std::vector<skh_ctx*> all;
+    skh_comm* comm = nullptr;                 // made on first use (stats over several GPUs)
+    int init(const GlobalOpts& g)
+    {
+        for (int d : g.devices) {
+            skh_ctx* x = nullptr;
+            if (skh_init(d, &x) != SKH_OK) return -1;
+            all.push_back(x);
+        }
+        c = all[0];
+        return 0;
+    }
+    ~Ctx()
+    {
+        drop_cached_blocks();
+        if (comm) skh_comm_destroy(comm);
+        for (skh_ctx* x : all) skh_destroy(x);
+    }
 };
 
 struct TwoBatches {
@@ -340,6 +359,8 @@ private:
 class BlockPipe {
     struct Block {
         skh_text* t = nullptr;
+        skh_ctx* ctx = nullptr;          // the GPU the block lives on
+        int dev_index = 0;               // its index in the command's device list
         uint64_t cap = 0, head = 0;      // buffer size; where the reader starts to fill
         uint64_t filled = 0;             // bytes the reader put at buffer + head
         bool eof = false;                // the file ended in (or right after) this block
@@ -364,7 +385,8 @@ class BlockPipe {
     };
     // everything the threads touch; outlives the object when the reader has to be left behind
     struct State {
-        skh_ctx* ctx = nullptr; std::string path;
+        std::vector<skh_ctx*> ctxs; std::string path;
+        size_t nblocks = 4;              // blocks in the round: 4, or two per GPU when that is more
         void* fh = nullptr; int fd = -1; uint64_t file_size = UINT64_MAX, file_pos = 0;
         Queue free_q, filled_q, parsed_q;
         std::vector<Block*> all;
@@ -397,13 +419,14 @@ public:
     }
 
 private:
-    static Block* new_block(State& s, uint64_t cap, bool grown)
+    static Block* new_block(State& s, uint64_t cap, bool grown, int dev_index)
     {
+        skh_ctx* ctx = s.ctxs[(size_t)dev_index];
         if (!grown) {
             Cache& c = cache();
             std::lock_guard<std::mutex> l(c.mu);
             for (size_t k = 0; k < c.blocks.size(); k++) {
-                if (c.blocks[k]->ordinary_for != cap) continue;
+                if (c.blocks[k]->ordinary_for != cap || c.blocks[k]->ctx != ctx) continue;
                 Block* b = c.blocks[k];
                 c.blocks.erase(c.blocks.begin() + (long)k);
                 b->head = headroom(*b);
@@ -413,8 +436,9 @@ private:
         }
         Block* b = new Block;
         b->ordinary_for = grown ? 0 : cap;
+        b->ctx = ctx; b->dev_index = dev_index;
         PhaseTimer pt(5);
-        if (skh_text_alloc(s.ctx, cap, &b->t) != SKH_OK) { s.fail(skh_last_error()); delete b; return nullptr; }
+        if (skh_text_alloc(ctx, cap, &b->t) != SKH_OK) { s.fail(skh_last_error()); delete b; return nullptr; }
         b->cap = skh_text_capacity(b->t);
         b->grown = grown;
         b->head = headroom(*b);
@@ -471,7 +495,7 @@ private:
             if (b->filled) prev = buf[b->filled - 1];
             // the block starts to cross the link now, while the block before it is parsed (not when
             // it can only be appended to a record that is still growing)
-            if (skh_text_upload(s.ctx, b->t, b->head, b->head_line ? b->filled : 0) != SKH_OK) {
+            if (skh_text_upload(b->ctx, b->t, b->head, b->head_line ? b->filled : 0) != SKH_OK) {
                 s.fail(skh_last_error());
                 break;
             }
@@ -504,7 +528,7 @@ private:
         // a file that made one block grow will make the others grow too: they go to the largest size
         // seen so far at once instead of doubling their way up (every step pins fresh memory)
         if (cap < s.largest_cap) cap = s.largest_cap;
-        Block* nb = new_block(s, cap, true);
+        Block* nb = new_block(s, cap, true, b->dev_index);
         if (!nb) return nullptr;
         if (nb->cap > s.largest_cap) s.largest_cap = nb->cap;
         for (auto& x : s.all) if (x == b) x = nb;
@@ -528,8 +552,9 @@ private:
         bool multiline = false;                             // FASTQ with wrapped records: blocks are rewritten (normalize_fastq)
         std::vector<uint8_t> norm;
         uint64_t lines_before = 0;
-        for (int k = 1; k < 4 && !s.stop; k++) {
-            Block* b = new_block(s, s.block_bytes, false);
+        // the blocks go round in the order they are made: dealt to the GPUs in turn
+        for (size_t k = 1; k < s.nblocks && !s.stop; k++) {
+            Block* b = new_block(s, s.block_bytes, false, (int)(k % s.ctxs.size()));
             if (!b) { s.stop = true; break; }
             s.all.push_back(b);
             s.free_q.push(b);
@@ -560,7 +585,7 @@ private:
                     // the tail does not fit in front of what was read, but the block holds both
                     memmove(skh_text_buffer(b->t) + tail.size(), skh_text_buffer(b->t) + b->head, b->filled);
                     b->head = tail.size();
-                    skh_text_upload(s.ctx, b->t, 0, 0);            // what the reader sent ahead lies elsewhere now
+                    skh_text_upload(b->ctx, b->t, 0, 0);           // what the reader sent ahead lies elsewhere now
                 } else if (tail.size() > b->head) {
                     // both go into a block of twice the size (half of it headroom), which stays in the round
                     Block* nb = replace_block(s, b, 2 * (tail.size() + b->filled));
@@ -606,7 +631,7 @@ private:
             skh_parse_result res;
             if (!multiline) {
                 PhaseTimer pt(1);
-                if (skh_text_parse_at(s.ctx, b->t, off, have, s.fastq ? SKH_FASTQ : SKH_FASTA, eof, &res) != SKH_OK) {
+                if (skh_text_parse_at(b->ctx, b->t, off, have, s.fastq ? SKH_FASTQ : SKH_FASTA, eof, &res) != SKH_OK) {
                     s.fail(skh_last_error());
                     break;
                 }
@@ -663,8 +688,8 @@ private:
                 }
                 memcpy(skh_text_buffer(b->t), norm.data(), norm.size());
                 PhaseTimer pt(1);
-                if (skh_text_upload(s.ctx, b->t, 0, 0) != SKH_OK ||
-                    skh_text_parse_at(s.ctx, b->t, 0, norm.size(), SKH_FASTQ, 1, &res) != SKH_OK) {
+                if (skh_text_upload(b->ctx, b->t, 0, 0) != SKH_OK ||
+                    skh_text_parse_at(b->ctx, b->t, 0, norm.size(), SKH_FASTQ, 1, &res) != SKH_OK) {
                     s.fail(skh_last_error());
                     break;
                 }
@@ -684,10 +709,11 @@ private:
     }
 
 public:
-    BlockPipe(skh_ctx* ctx, const std::string& path, uint64_t block_bytes) : s_(std::make_shared<State>())
+    BlockPipe(const std::vector<skh_ctx*>& ctxs, const std::string& path, uint64_t block_bytes) : s_(std::make_shared<State>())
     {
         State& s = *s_;
-        s.ctx = ctx; s.path = path;
+        s.ctxs = ctxs; s.path = path;
+        s.nblocks = std::max<size_t>(4, 2 * ctxs.size());
         if (path != "-") {
             s.fd = open(path.c_str(), O_RDONLY);
             if (s.fd < 0) { s.err = "open " + path + ": no such file or directory"; return; }
@@ -703,7 +729,7 @@ public:
         if (s.fd < 0 && !s.fh) { s.err = "open " + path + ": no such file or directory"; return; }
         if (s.fh) gzbuffer((gzFile)s.fh, 1 << 20);
         // the first block here, the other three by the parser thread while the reader fills this one
-        Block* b = new_block(s, block_bytes, false);
+        Block* b = new_block(s, block_bytes, false, 0);
         if (!b) return;
         s.chunk = b->cap - b->head;
         s.block_bytes = block_bytes;
@@ -731,7 +757,7 @@ public:
             if (b->ordinary_for) {
                 Cache& c = cache();
                 std::lock_guard<std::mutex> l(c.mu);
-                if (c.blocks.size() < 4) { c.blocks.push_back(b); continue; }
+                if (c.blocks.size() < s.nblocks) { c.blocks.push_back(b); continue; }
             }
             if (b->t) skh_text_free(b->t);
             delete b;
@@ -747,6 +773,7 @@ public:
     std::string error() { return s_->error(); }
     bool is_fastq() const { return s_->fastq; }
     skh_text* block() const { return cur_ ? cur_->t : nullptr; }
+    int device_index() const { return cur_ ? cur_->dev_index : 0; }     // of the current block, in the device list
 
     // The next parsed block (at least one record), in file order.  false: end of the file or error.
     bool next(skh_parse_result& res)
@@ -793,13 +820,13 @@ int first_record_alphabet(skh_ctx* ctx, skh_text* t, const GlobalOpts& g, int fo
 }
 
 // `seq` with parse and output formatting on the GPU (seq.go:114-280 a block at a time)
-int seq_text_path(const GlobalOpts& g, const SeqOpts& o, const std::vector<std::string>& files, skh_ctx* ctx, Sink& out)
+int seq_text_path(const GlobalOpts& g, const SeqOpts& o, const std::vector<std::string>& files, const std::vector<skh_ctx*>& ctxs, Sink& out)
 {
     bool is_fastq = false, check_type = true;        // seq.go:105-106: decided once, by the first printed record
-    bool warn_once = true;                           // seq.go:107: one "already RNA / DNA" warning per run
     std::vector<uint64_t> offs;
     for (const std::string& file : files) {
-        BlockPipe tb(ctx, file, g.text_block_bytes);
+        bool warn_once = true;                       // seq.go:118: one "already RNA / DNA" warning per file
+        BlockPipe tb(ctxs, file, g.text_block_bytes);
         if (!tb.ok()) return fatal(tb.error());
         uint8_t lut[256], valid[256], gap_pre[256];
         bool lut_ready = false, any_map = false;
@@ -815,7 +842,7 @@ int seq_text_path(const GlobalOpts& g, const SeqOpts& o, const std::vector<std::
             uint64_t nbytes = 0;
             {
                 PhaseTimer pt(3);
-                if (skh_text_output_wait(ctx, BlockPipe::text_of(held), &text, &nbytes) != SKH_OK) return fatal(skh_last_error());
+                if (skh_text_output_wait(skh_text_ctx(BlockPipe::text_of(held)), BlockPipe::text_of(held), &text, &nbytes) != SKH_OK) return fatal(skh_last_error());
             }
             { PhaseTimer pt(4); out.write(text, nbytes); }
             tb.release(held);
@@ -824,6 +851,7 @@ int seq_text_path(const GlobalOpts& g, const SeqOpts& o, const std::vector<std::
         };
         auto one_block = [&]() -> int {
             skh_text* t = tb.block();
+            skh_ctx* ctx = skh_text_ctx(t);              // the GPU this block was dealt to
             if (res.nrec == 0) { tb.advance(res); return 0; }
             if (ab < 0 && (o.complement || o.validate || o.dna2rna || o.rna2dna)) {
                 std::string err;
@@ -931,7 +959,8 @@ int seq_text_path(const GlobalOpts& g, const SeqOpts& o, const std::vector<std::
                     if (!is_fastq) return fatal("FASTA format has no quality. So do not just use flag -q (--qual)");
                     f.print_name = 0; f.print_seq = 0; f.print_qual = 1; f.plus_line = 0;
                 }
-                if (f.print_qual && !tb.is_fastq()) f.print_qual = 0;      // a FASTA file after a FASTQ one
+                // (a FASTA file after a FASTQ one keeps the FASTQ layout: "+" and an empty quality line,
+                // seq.go:140-149,258-276; the formatter prints that for a block without a quality plane)
                 f.only_id = o.only_id;
                 f.mark = is_fastq ? '@' : '>';
                 {
@@ -962,11 +991,11 @@ int cmd_seq(const GlobalOpts& g, const SeqOpts& o, const std::vector<std::string
 {
     Ctx ctx;
     const double t_init = Phases::now();
-    if (skh_init(g.device, &ctx.c) != SKH_OK) return fatal(skh_last_error());
+    if (ctx.init(g) != 0) return fatal(skh_last_error());
     if (g_phases.on) fprintf(stderr, "[timing] skh_init %.3f s\n", Phases::now() - t_init);
     Sink out(g.out_file);
     if (!out.ok()) return fatal("open " + g.out_file + ": cannot create");
-    if (!g.host_parse) return seq_text_path(g, o, files, ctx.c, out);
+    if (!g.host_parse) return seq_text_path(g, o, files, ctx.all, out);
     if (o.remove_gaps || o.lower_case || o.upper_case || o.dna2rna || o.rna2dna)
         return fatal("--host-parse does not know -g, -l, -u, --dna2rna, --rna2dna (they are done on the GPU text path)");
     bool is_fastq = false, check_type = true;        // seq.go:105-106: decided once, by the first record
@@ -1005,7 +1034,8 @@ int cmd_seq(const GlobalOpts& g, const SeqOpts& o, const std::vector<std::string
                 if (ps) { write_wrapped(out, bt.seq() + off[r], len, width); out.put('\n'); }
                 if (pq) {
                     if (!o.only_qual) out.puts("+\n");
-                    if (bt.qual()) write_wrapped(out, bt.qual() + off[r], len, width);
+                    // (a FASTA file after a FASTQ one has no qualities, though the batch, kept from that file, has a plane)
+                    if (bt.qual() && rd.is_fastq()) write_wrapped(out, bt.qual() + off[r], len, width);
                     out.put('\n');
                 }
             }
@@ -1080,7 +1110,7 @@ int cmd_seq(const GlobalOpts& g, const SeqOpts& o, const std::vector<std::string
 int cmd_fx2tab(const GlobalOpts& g, const Fx2tabOpts& o, const std::vector<std::string>& files)
 {
     Ctx ctx;
-    if (skh_init(g.device, &ctx.c) != SKH_OK) return fatal(skh_last_error());
+    if (ctx.init(g) != 0) return fatal(skh_last_error());
     Sink out(g.out_file);
     if (!out.ok()) return fatal("open " + g.out_file + ": cannot create");
 
@@ -1143,7 +1173,7 @@ int cmd_fx2tab(const GlobalOpts& g, const Fx2tabOpts& o, const std::vector<std::
     }
     if (device_rows) {
         for (const std::string& file : files) {
-            BlockPipe tb(ctx.c, file, g.text_block_bytes);
+            BlockPipe tb(ctx.all, file, g.text_block_bytes);
             if (!tb.ok()) return fatal(tb.error());
             skh_parse_result res;
             // the rows of a block are downloaded while the next block is counted: `held` is the block
@@ -1155,7 +1185,7 @@ int cmd_fx2tab(const GlobalOpts& g, const Fx2tabOpts& o, const std::vector<std::
                 uint64_t nbytes = 0;
                 {
                     PhaseTimer pt(3);
-                    if (skh_text_output_wait(ctx.c, BlockPipe::text_of(held), &text, &nbytes) != SKH_OK) return fatal(skh_last_error());
+                    if (skh_text_output_wait(skh_text_ctx(BlockPipe::text_of(held)), BlockPipe::text_of(held), &text, &nbytes) != SKH_OK) return fatal(skh_last_error());
                 }
                 { PhaseTimer pt(4); out.write(text, nbytes); }
                 tb.release(held);
@@ -1168,19 +1198,19 @@ int cmd_fx2tab(const GlobalOpts& g, const Fx2tabOpts& o, const std::vector<std::
                 {
                     PhaseTimer pt(2);
                     for (size_t ps = 0; ps < npass; ps++)
-                        if (skh_text_count(ctx.c, t, pass_table[ps].data(), pass_nclass[ps], (uint32_t)ps) != SKH_OK)
+                        if (skh_text_count(skh_text_ctx(t), t, pass_table[ps].data(), pass_nclass[ps], (uint32_t)ps) != SKH_OK)
                             return fatal(skh_last_error());
                 }
                 if (o.alphabet_col) {                          // fx2tab.go:145-147
                     PhaseTimer pt(2);
-                    if (skh_text_letters(ctx.c, t) != SKH_OK) return fatal(skh_last_error());
+                    if (skh_text_letters(skh_text_ctx(t), t) != SKH_OK) return fatal(skh_last_error());
                 }
                 tf.alphabet = o.alphabet_col ? 1 : 0;
                 tf.print_seq = !o.only_name;
                 tf.print_qual = !o.only_name && tb.is_fastq();
                 {
                     PhaseTimer pt(3);
-                    if (skh_text_format_tab_submit(ctx.c, t, &tf) != SKH_OK) return fatal(skh_last_error());
+                    if (skh_text_format_tab_submit(skh_text_ctx(t), t, &tf) != SKH_OK) return fatal(skh_last_error());
                 }
                 if (int rc = flush_held()) return rc;
                 held = tb.hold();
@@ -1347,7 +1377,7 @@ int cmd_stats(const GlobalOpts& g, const StatsOpts& o, const std::vector<std::st
         is_gap[ch] = 1;
     }
     Ctx ctx;
-    if (skh_init(g.device, &ctx.c) != SKH_OK) return fatal(skh_last_error());
+    if (ctx.init(g) != 0) return fatal(skh_last_error());
     Sink out(g.out_file);
     if (!out.ok()) return fatal("open " + g.out_file + ": cannot create");
 
@@ -1357,10 +1387,11 @@ int cmd_stats(const GlobalOpts& g, const StatsOpts& o, const std::vector<std::st
     for (const std::string& file : files) {
         if (!g.host_parse) {
             // file text parsed on the GPU: per block the totals kernel, and for -a the lengths
-            BlockPipe tb(ctx.c, file, g.text_block_bytes);
+            BlockPipe tb(ctx.all, file, g.text_block_bytes);
             if (!tb.ok()) return fatal(tb.error());
-            skh_stats_partial tot;
-            skh_stats_init(&tot);
+            // one partial per GPU the blocks are dealt to; merged at the end of the file
+            std::vector<skh_stats_partial> part(ctx.all.size());
+            for (auto& p : part) skh_stats_init(&p);
             std::vector<int64_t> lens;
             std::vector<uint64_t> offs;
             bool fastq_first = false, first = true;
@@ -1372,24 +1403,30 @@ int cmd_stats(const GlobalOpts& g, const StatsOpts& o, const std::vector<std::st
                 if (first || o.all) {
                     const uint64_t cnt = o.all ? res.nrec + 1 : 2;
                     offs.resize(cnt);
-                    if (skh_text_offsets(ctx.c, t, 0, cnt, offs.data()) != SKH_OK) return fatal(skh_last_error());
+                    if (skh_text_offsets(skh_text_ctx(t), t, 0, cnt, offs.data()) != SKH_OK) return fatal(skh_last_error());
                 }
                 if (first) {
                     fastq_first = tb.is_fastq() && offs[1] > offs[0];                 // stat.go:107-113
                     std::string err;
-                    ab = first_record_alphabet(ctx.c, t, g, -1, err);
+                    ab = first_record_alphabet(skh_text_ctx(t), t, g, g.alphabet, err);     // stat.go:87: config.Alphabet goes to the reader
                     if (ab < 0) return fatal(err);
                     first = false;
                 }
-                if (skh_text_stats(ctx.c, t, is_gap, &tot) != SKH_OK) return fatal(skh_last_error());
+                if (skh_text_stats(skh_text_ctx(t), t, is_gap, &part[(size_t)tb.device_index()]) != SKH_OK) return fatal(skh_last_error());
                 if (o.all) for (uint64_t r = 0; r < res.nrec; r++) lens.push_back((int64_t)(offs[r + 1] - offs[r]));
                 tb.advance(res);
             }
             if (!tb.error().empty()) return fatal(tb.error());
+            if (part.size() > 1) {
+                // the path's one collective: the per-GPU totals all-reduced over RCCL (stat.go:106-125 across GPUs)
+                if (!ctx.comm && skh_comm_init_all(ctx.all.data(), (int)ctx.all.size(), &ctx.comm) != SKH_OK) return fatal(skh_last_error());
+                if (skh_stats_allreduce(ctx.comm, part.data()) != SKH_OK) return fatal(skh_last_error());
+            }
+            const skh_stats_partial tot = part[0];
             infos.push_back(make_stat_info(file, first, fastq_first, ab, tot, lens, o.all));
             continue;
         }
-        FastxReader rd(ctx.c, file, Auto, g.guess_len);
+        FastxReader rd(ctx.c, file, g.alphabet, g.guess_len);
         if (!rd.ok()) return fatal(rd.error());
         skh_stats_partial tot;
         skh_stats_init(&tot);
@@ -1629,7 +1666,7 @@ int cmd_subseq(const GlobalOpts& g, const SubseqOpts& o, const std::vector<std::
     }
 
     Ctx ctx;
-    if (skh_init(g.device, &ctx.c) != SKH_OK) return fatal(skh_last_error());
+    if (ctx.init(g) != 0) return fatal(skh_last_error());
     Sink out(g.out_file);
     if (!out.ok()) return fatal("open " + g.out_file + ": cannot create");
     std::vector<uint64_t> offs, npos, out_npos;
@@ -1637,7 +1674,7 @@ int cmd_subseq(const GlobalOpts& g, const SubseqOpts& o, const std::vector<std::
     std::vector<skh_slice> slices;
     std::string names;
     for (const std::string& file : files) {
-        BlockPipe tb(ctx.c, file, g.text_block_bytes);
+        BlockPipe tb(ctx.all, file, g.text_block_bytes);
         if (!tb.ok()) return fatal(tb.error());
         uint8_t lut[256];
         int ab = -1;
@@ -1652,20 +1689,20 @@ int cmd_subseq(const GlobalOpts& g, const SubseqOpts& o, const std::vector<std::
             f.print_name = 1; f.print_seq = 1; f.plus_line = 1;
             if (by_region) {
                 PhaseTimer pt(2);
-                if (skh_text_subseq(ctx.c, t, nullptr, 0, start, end, 0, nullptr, nullptr, 0, nullptr, nullptr) != SKH_OK)
+                if (skh_text_subseq(skh_text_ctx(t), t, nullptr, 0, start, end, 0, nullptr, nullptr, 0, nullptr, nullptr) != SKH_OK)
                     return fatal(skh_last_error());
                 f.print_qual = tb.is_fastq(); f.mark = tb.is_fastq() ? '@' : '>';
                 f.empty_as_fasta = 1;                                         // Record.FormatToWriter: layout per record
             } else if (by_gtf || by_bed) {
                 if (ab < 0) {
                     std::string err;
-                    ab = first_record_alphabet(ctx.c, t, g, g.alphabet, err);
+                    ab = first_record_alphabet(skh_text_ctx(t), t, g, g.alphabet, err);
                     if (ab < 0) return fatal(err);
                     skh_pair_table(ab, lut);
                 }
                 offs.resize(res.nrec + 1); npos.resize(res.nrec); nlen.resize(res.nrec);
-                if (skh_text_offsets(ctx.c, t, 0, res.nrec + 1, offs.data()) != SKH_OK) return fatal(skh_last_error());
-                if (skh_text_names(ctx.c, t, 0, res.nrec, npos.data(), nlen.data()) != SKH_OK) return fatal(skh_last_error());
+                if (skh_text_offsets(skh_text_ctx(t), t, 0, res.nrec + 1, offs.data()) != SKH_OK) return fatal(skh_last_error());
+                if (skh_text_names(skh_text_ctx(t), t, 0, res.nrec, npos.data(), nlen.data()) != SKH_OK) return fatal(skh_last_error());
                 slices.clear(); names.clear(); out_npos.clear(); out_nlen.clear();
                 const uint8_t* text = skh_text_buffer(t);
                 for (uint64_t r = 0; r < res.nrec; r++) {
@@ -1706,7 +1743,7 @@ int cmd_subseq(const GlobalOpts& g, const SubseqOpts& o, const std::vector<std::
                 }
                 if (slices.empty()) { tb.advance(res); continue; }
                 PhaseTimer pt(2);
-                if (skh_text_subseq(ctx.c, t, slices.data(), slices.size(), 0, 0, 0, lut, (const uint8_t*)names.data(),
+                if (skh_text_subseq(skh_text_ctx(t), t, slices.data(), slices.size(), 0, 0, 0, lut, (const uint8_t*)names.data(),
                                     names.size(), out_npos.data(), out_nlen.data()) != SKH_OK)
                     return fatal(skh_last_error());
                 f.print_qual = 0; f.mark = '>';                               // fastx.NewRecord without qualities
@@ -1718,7 +1755,7 @@ int cmd_subseq(const GlobalOpts& g, const SubseqOpts& o, const std::vector<std::
             uint64_t nbytes = 0;
             {
                 PhaseTimer pt(3);
-                if (skh_text_format_seq(ctx.c, t, &f, &text, &nbytes) != SKH_OK) return fatal(skh_last_error());
+                if (skh_text_format_seq(skh_text_ctx(t), t, &f, &text, &nbytes) != SKH_OK) return fatal(skh_last_error());
             }
             { PhaseTimer pt(4); out.write(text, nbytes); }
             tb.advance(res);
@@ -1812,7 +1849,7 @@ int cmd_convert(const GlobalOpts& g, const ConvertOpts& o, const std::vector<std
         if (skh_quality_table(from, o.to, o.force, lut, valid, &identity) != SKH_OK) return fatal(skh_last_error());
     }
     Ctx ctx;
-    if (skh_init(g.device, &ctx.c) != SKH_OK) return fatal(skh_last_error());
+    if (ctx.init(g) != 0) return fatal(skh_last_error());
     Sink out(g.out_file);
     if (!out.ok()) return fatal("open " + g.out_file + ": cannot create");
     std::vector<uint64_t> offs;
@@ -1826,9 +1863,9 @@ int cmd_convert(const GlobalOpts& g, const ConvertOpts& o, const std::vector<std
     auto guess_from = [&](skh_text* t, uint64_t nrec, bool at_eof, bool& skip) -> int {
         const uint64_t look = std::min<uint64_t>(nrec, (uint64_t)(o.nrecords - n));
         offs.resize(look + 1);
-        if (skh_text_offsets(ctx.c, t, 0, look + 1, offs.data()) != SKH_OK) return fatal(skh_last_error());
+        if (skh_text_offsets(skh_text_ctx(t), t, 0, look + 1, offs.data()) != SKH_OK) return fatal(skh_last_error());
         qual.resize(offs[look] ? offs[look] : 1);
-        if (offs[look] && skh_text_quality(ctx.c, t, 0, offs[look], qual.data()) != SKH_OK) return fatal(skh_last_error());
+        if (offs[look] && skh_text_quality(skh_text_ctx(t), t, 0, offs[look], qual.data()) != SKH_OK) return fatal(skh_last_error());
         for (uint64_t r = 0; r < look; r++) {
             const unsigned set = guess_quality_encoding(qual.data() + offs[r], offs[r + 1] - offs[r], o.n_most_common);
             for (int e = 0; e < 6; e++) if (set & (1u << e)) marks[e]++;
@@ -1859,7 +1896,7 @@ int cmd_convert(const GlobalOpts& g, const ConvertOpts& o, const std::vector<std
                 uint64_t nbytes = 0;
                 {
                     PhaseTimer pt(3);
-                    if (skh_text_output_wait(ctx.c, BlockPipe::text_of(held), &text, &nbytes) != SKH_OK) return fatal(skh_last_error());
+                    if (skh_text_output_wait(skh_text_ctx(BlockPipe::text_of(held)), BlockPipe::text_of(held), &text, &nbytes) != SKH_OK) return fatal(skh_last_error());
                 }
                 { PhaseTimer pt(4); out.write(text, nbytes); }
                 tb.release(held);
@@ -1890,15 +1927,15 @@ int cmd_convert(const GlobalOpts& g, const ConvertOpts& o, const std::vector<std
             if (o.dry_run) { stop = true; return 0; }
             if (!identity) {
                 skh_validate_result vr;
-                if (skh_text_validate_quality(ctx.c, t, valid, &vr) != SKH_OK) return fatal(skh_last_error());
+                if (skh_text_validate_quality(skh_text_ctx(t), t, valid, &vr) != SKH_OK) return fatal(skh_last_error());
                 if (vr.found) {
                     pending_error = std::string("seq: invalid ") + (from == SKH_Q_SOLEXA ? "Solexa" : "Phred") + " quality";
-                    if (skh_text_truncate(ctx.c, t, vr.record) != SKH_OK) return fatal(skh_last_error());
+                    if (skh_text_truncate(skh_text_ctx(t), t, vr.record) != SKH_OK) return fatal(skh_last_error());
                     res.nrec = vr.record;
                     if (res.nrec == 0) { stop = true; return 0; }
                 }
                 PhaseTimer pt(2);
-                if (skh_text_map_quality(ctx.c, t, lut) != SKH_OK) return fatal(skh_last_error());
+                if (skh_text_map_quality(skh_text_ctx(t), t, lut) != SKH_OK) return fatal(skh_last_error());
             }
             skh_seq_format f;
             memset(&f, 0, sizeof f);
@@ -1911,7 +1948,7 @@ int cmd_convert(const GlobalOpts& g, const ConvertOpts& o, const std::vector<std
                 uint64_t nbytes = 0;
                 {
                     PhaseTimer pt(3);
-                    if (skh_text_format_seq(ctx.c, t, &f, &text, &nbytes) != SKH_OK) return fatal(skh_last_error());
+                    if (skh_text_format_seq(skh_text_ctx(t), t, &f, &text, &nbytes) != SKH_OK) return fatal(skh_last_error());
                 }
                 { PhaseTimer pt(4); out.write(text, nbytes); }
                 if (pending_error.empty()) tb.advance(res);
@@ -1919,7 +1956,7 @@ int cmd_convert(const GlobalOpts& g, const ConvertOpts& o, const std::vector<std
                 // the download of this block's output runs beside the next block's kernels
                 {
                     PhaseTimer pt(3);
-                    if (skh_text_format_seq_submit(ctx.c, t, &f) != SKH_OK) return fatal(skh_last_error());
+                    if (skh_text_format_seq_submit(skh_text_ctx(t), t, &f) != SKH_OK) return fatal(skh_last_error());
                 }
                 if (int rc = flush_held()) return rc;
                 held = tb.hold();
@@ -1963,7 +2000,7 @@ int cmd_convert(const GlobalOpts& g, const ConvertOpts& o, const std::vector<std
             if (!tb.error().empty()) return fatal(tb.error());
         }
         if (skip) continue;
-        BlockPipe tb(ctx.c, file, g.text_block_bytes);
+        BlockPipe tb(ctx.all, file, g.text_block_bytes);
         if (!tb.ok()) return fatal(tb.error());
         if (int rc = convert_blocks(tb)) return rc;
     }

@@ -97,6 +97,8 @@ struct GlobalOpts {
     bool quiet = false;
     size_t guess_len = 10000;     // --alphabet-guess-seq-length
     int device = 0;               // --device (extension: which GPU)
+    std::vector<int> devices;     // --gpus N (devices device .. device+N-1) or --devices a,b,c: the GPUs the text
+                                  // blocks of a file are dealt to in turn (always at least one entry)
     uint64_t batch_bytes = 256ull << 20, batch_records = 4ull << 20;
     uint64_t text_block_bytes = 32ull << 20;   // text path: file bytes per block (--batch-bytes overrides)
     bool host_parse = false;      // --host-parse: records are scanned and printed by the host

@@ -97,7 +97,8 @@ int usage()
             "                    [-u N] [-d N] [-f] [global flags] [files...]\n"
             "  seqkit-hip convert [--from ENC] [--to ENC] [-f] [-d] [-n N] [-N N] [-F frac] [global flags] [files...]\n\n"
             "Global flags: -t/--seq-type dna|rna|protein|unlimit|auto, -j/--threads N, -w/--line-width N,\n"
-            "  -o/--out-file FILE, --quiet, --alphabet-guess-seq-length N, --device N,\n"
+            "  -o/--out-file FILE, --quiet, --alphabet-guess-seq-length N, --device N, --gpus N | --devices a,b,..\n"
+            "  (text blocks dealt to several GPUs; stats totals merged by an RCCL all-reduce),\n"
             "  --batch-bytes N (text block / batch size), --host-parse (scan and print records on the host)\n");
     return 255;
 }
@@ -115,6 +116,7 @@ int main(int argc, char** argv)
     Parser p;
     p.flags = {{"t", "seq-type", true}, {"j", "threads", true}, {"w", "line-width", true}, {"o", "out-file", true},
                {nullptr, "quiet", false}, {nullptr, "alphabet-guess-seq-length", true}, {nullptr, "device", true},
+               {nullptr, "gpus", true}, {nullptr, "devices", true},
                {nullptr, "id-regexp", true}, {nullptr, "id-ncbi", false},
                {nullptr, "batch-bytes", true}, {nullptr, "batch-records", true}, {nullptr, "host-parse", false}};
     if (is_seq) {
@@ -160,6 +162,17 @@ int main(int argc, char** argv)
     if (gl > 0 && gl < 1000) return fatal("value of flag --alphabet-guess-seq-length too small, should >= 1000");
     g.guess_len = (size_t)gl;
     g.device = atoi(p.value("device", "0").c_str());
+    // --gpus N: the file's text blocks are dealt to N GPUs in turn (records are independent; `stats`
+    // merges the per-GPU totals with one RCCL all-reduce); --devices lists the ordinals instead
+    if (p.has("devices")) {
+        for (const std::string& d : p.values("devices")) g.devices.push_back(atoi(d.c_str()));
+    } else {
+        const int n = atoi(p.value("gpus", "1").c_str());
+        if (n < 1 || n > 64) return fatal("value of flag --gpus should be between 1 and 64");
+        for (int k = 0; k < n; k++) g.devices.push_back(g.device + k);
+    }
+    if (g.devices.empty()) return fatal("value of flag --devices should not be empty");
+    g.device = g.devices[0];
     g.batch_bytes = strtoull(p.value("batch-bytes", "268435456").c_str(), nullptr, 10);
     g.batch_records = strtoull(p.value("batch-records", "4194304").c_str(), nullptr, 10);
     g.host_parse = p.has("host-parse");

@@ -40,6 +40,38 @@ def split_record(length, nparts, align=16):
     return [(cuts[i], cuts[i + 1], length - cuts[i + 1]) for i in range(nparts)]
 
 
+def plan_pieces(lengths, nparts, align=16):
+    """Byte-volume sharding with cuts inside records: rank k gets the pieces [(record, a, b)] that
+    cover bytes [k * total / nparts, (k+1) * total / nparts) of the batch, a cut inside a record moved
+    down to a multiple of `align` within that record.  A piece (r, a, b) is a record of its own for the
+    rank (`split_record`'s rule: its reverse-complement belongs at [L-b, L-a) of record r's result).
+    Pieces of all ranks, in rank order, tile every record exactly once."""
+    lengths = [int(x) for x in lengths]
+    total = sum(lengths)
+    bounds = [total * k // nparts for k in range(nparts + 1)]
+    out = [[] for _ in range(nparts)]
+    start = 0                      # plane position of the current record
+    k = 0
+    for r, L in enumerate(lengths):
+        a = 0
+        while a < L or (L == 0 and a == 0):
+            if L == 0:
+                out[min(k, nparts - 1)].append((r, 0, 0))
+                break
+            while k < nparts - 1 and start + a >= bounds[k + 1]:
+                k += 1
+            b = L
+            if k < nparts - 1 and start + L > bounds[k + 1]:
+                b = (bounds[k + 1] - start) // align * align
+                if b <= a:         # the cut would fall at or before the piece's start: the next rank takes it from a
+                    k += 1
+                    continue
+            out[k].append((r, a, b))
+            a = b
+        start += L
+    return out
+
+
 def allreduce_stats(partial, group=None):
     """partial: int64 tensor [num, len_sum, gap_sum, len_min, len_max] of this rank (layout of
     skh_stats_partial).  Returns the file-level totals on every rank: two small all-reduces

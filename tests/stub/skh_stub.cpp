@@ -262,10 +262,12 @@ int skh_text_alloc(skh_ctx* ctx, uint64_t block_bytes, skh_text** out)
 void skh_text_free(skh_text* t) { delete t; }
 uint8_t* skh_text_buffer(skh_text* t) { return t ? t->h_text.data() : nullptr; }
 uint64_t skh_text_capacity(const skh_text* t) { return t ? t->cap : 0; }
+skh_ctx* skh_text_ctx(const skh_text* t) { return t ? t->ctx : nullptr; }
 
-int skh_text_upload(skh_ctx*, skh_text* t, uint64_t offset, uint64_t nbytes)
+int skh_text_upload(skh_ctx* cx, skh_text* t, uint64_t offset, uint64_t nbytes)
 {
     if (!t) return fail(SKH_EINVAL, "NULL argument");
+    if (t->ctx != cx) return fail(SKH_EINVAL, "the text block belongs to another context");
     if (offset > t->cap || nbytes > t->cap - offset) return fail(SKH_ECAPACITY, "range beyond the block's buffer");
     t->up_bytes = 0;
     if (nbytes == 0) return SKH_OK;
@@ -275,9 +277,10 @@ int skh_text_upload(skh_ctx*, skh_text* t, uint64_t offset, uint64_t nbytes)
     return SKH_OK;
 }
 
-int skh_text_parse_at(skh_ctx*, skh_text* t, uint64_t off, uint64_t n, int format, int final, skh_parse_result* res)
+int skh_text_parse_at(skh_ctx* cx, skh_text* t, uint64_t off, uint64_t n, int format, int final, skh_parse_result* res)
 {
     if (!t || !res) return fail(SKH_EINVAL, "NULL argument");
+    if (t->ctx != cx) return fail(SKH_EINVAL, "the text block belongs to another context");
     if (off > t->cap || n > t->cap - off) return fail(SKH_ECAPACITY, "text block larger than its buffer");
     if (format != SKH_FASTA && format != SKH_FASTQ) return fail(SKH_EINVAL, "format must be SKH_FASTA or SKH_FASTQ");
     // the "device" text: what was uploaded ahead plus the bytes around it, as the library composes it
@@ -394,31 +397,35 @@ int skh_text_parse(skh_ctx* c, skh_text* t, uint64_t n, int format, int final, s
     return skh_text_parse_at(c, t, 0, n, format, final, out);
 }
 
-int skh_text_offsets(skh_ctx*, skh_text* t, uint64_t first, uint64_t count, uint64_t* offsets)
+int skh_text_offsets(skh_ctx* cx, skh_text* t, uint64_t first, uint64_t count, uint64_t* offsets)
 {
     if (!t || !offsets) return fail(SKH_EINVAL, "NULL argument");
+    if (t->ctx != cx) return fail(SKH_EINVAL, "the text block belongs to another context");
     if (first + count > t->nrec + 1) return fail(SKH_EINVAL, "offset range beyond the block's records");
     memcpy(offsets, t->offs.data() + first, count * 8);
     return SKH_OK;
 }
-int skh_text_sequence(skh_ctx*, skh_text* t, uint64_t first_byte, uint64_t count, uint8_t* dst)
+int skh_text_sequence(skh_ctx* cx, skh_text* t, uint64_t first_byte, uint64_t count, uint8_t* dst)
 {
     if (!t || (!dst && count)) return fail(SKH_EINVAL, "NULL argument");
+    if (t->ctx != cx) return fail(SKH_EINVAL, "the text block belongs to another context");
     if (first_byte + count > t->offs[t->nrec]) return fail(SKH_EINVAL, "byte range beyond the block's sequence");
     if (count) memcpy(dst, t->seq.data() + first_byte, count);
     return SKH_OK;
 }
-int skh_text_quality(skh_ctx*, skh_text* t, uint64_t first_byte, uint64_t count, uint8_t* dst)
+int skh_text_quality(skh_ctx* cx, skh_text* t, uint64_t first_byte, uint64_t count, uint8_t* dst)
 {
     if (!t || (!dst && count)) return fail(SKH_EINVAL, "NULL argument");
+    if (t->ctx != cx) return fail(SKH_EINVAL, "the text block belongs to another context");
     if (!t->fastq) return fail(SKH_EINVAL, "a FASTA block has no qualities");
     if (first_byte + count > t->offs[t->nrec]) return fail(SKH_EINVAL, "byte range beyond the block's qualities");
     if (count) memcpy(dst, t->qual.data() + first_byte, count);
     return SKH_OK;
 }
-int skh_text_revcomp(skh_ctx*, skh_text* t, const uint8_t* lut, int do_reverse, int reverse_qual)
+int skh_text_revcomp(skh_ctx* cx, skh_text* t, const uint8_t* lut, int do_reverse, int reverse_qual)
 {
     if (!t) return fail(SKH_EINVAL, "NULL argument");
+    if (t->ctx != cx) return fail(SKH_EINVAL, "the text block belongs to another context");
     if (t->transformed) return fail(SKH_EINVAL, "block was already transformed");
     if (t->nrec == 0 || (!lut && !do_reverse)) return SKH_OK;
     ora_batch_transform(t->seq.data(), (t->fastq && do_reverse && reverse_qual) ? t->qual.data() : nullptr,
@@ -426,38 +433,43 @@ int skh_text_revcomp(skh_ctx*, skh_text* t, const uint8_t* lut, int do_reverse, 
     t->transformed = true;
     return SKH_OK;
 }
-int skh_text_map_quality(skh_ctx*, skh_text* t, const uint8_t lut[256])
+int skh_text_map_quality(skh_ctx* cx, skh_text* t, const uint8_t lut[256])
 {
     if (!t || !lut) return fail(SKH_EINVAL, "NULL argument");
+    if (t->ctx != cx) return fail(SKH_EINVAL, "the text block belongs to another context");
     if (!t->fastq) return fail(SKH_EINVAL, "a FASTA block has no qualities");
     if (t->transformed) return fail(SKH_EINVAL, "block was already transformed");
     for (uint64_t i = 0; i < t->offs[t->nrec]; i++) t->qual[i] = lut[t->qual[i]];
     t->transformed = t->nrec != 0;
     return SKH_OK;
 }
-int skh_text_validate(skh_ctx*, skh_text* t, const uint8_t valid[256], uint64_t limit, skh_validate_result* out)
+int skh_text_validate(skh_ctx* cx, skh_text* t, const uint8_t valid[256], uint64_t limit, skh_validate_result* out)
 {
     if (!t || !valid || !out) return fail(SKH_EINVAL, "NULL argument");
+    if (t->ctx != cx) return fail(SKH_EINVAL, "the text block belongs to another context");
     validate_of(t->seq.data(), t->offs.data(), t->nrec, valid, limit, out);
     return SKH_OK;
 }
-int skh_text_validate_quality(skh_ctx*, skh_text* t, const uint8_t valid[256], skh_validate_result* out)
+int skh_text_validate_quality(skh_ctx* cx, skh_text* t, const uint8_t valid[256], skh_validate_result* out)
 {
     if (!t || !valid || !out) return fail(SKH_EINVAL, "NULL argument");
+    if (t->ctx != cx) return fail(SKH_EINVAL, "the text block belongs to another context");
     if (!t->fastq) return fail(SKH_EINVAL, "a FASTA block has no qualities");
     validate_of(t->qual.data(), t->offs.data(), t->nrec, valid, 0, out);
     return SKH_OK;
 }
-int skh_text_truncate(skh_ctx*, skh_text* t, uint64_t nrec)
+int skh_text_truncate(skh_ctx* cx, skh_text* t, uint64_t nrec)
 {
     if (!t) return fail(SKH_EINVAL, "NULL argument");
+    if (t->ctx != cx) return fail(SKH_EINVAL, "the text block belongs to another context");
     if (nrec > t->nrec) return fail(SKH_EINVAL, "cannot truncate to more records than the block holds");
     t->nrec = nrec;
     return SKH_OK;
 }
-int skh_text_names(skh_ctx*, skh_text* t, uint64_t first, uint64_t count, uint64_t* pos, uint32_t* len)
+int skh_text_names(skh_ctx* cx, skh_text* t, uint64_t first, uint64_t count, uint64_t* pos, uint32_t* len)
 {
     if (!t || ((!pos || !len) && count)) return fail(SKH_EINVAL, "NULL argument");
+    if (t->ctx != cx) return fail(SKH_EINVAL, "the text block belongs to another context");
     if (first + count > t->nrec) return fail(SKH_EINVAL, "record range beyond the block");
     for (uint64_t i = 0; i < count; i++) {
         pos[i] = t->npos[first + i] + (t->names_external ? 0 : t->text_off);
@@ -471,9 +483,10 @@ int skh_text_name(skh_ctx* c, skh_text* t, uint64_t record, uint64_t* pos, uint3
     if (!t || record >= t->nrec) return fail(SKH_EINVAL, "record beyond the block");
     return skh_text_names(c, t, record, 1, pos, len);
 }
-int skh_text_count(skh_ctx*, skh_text* t, const uint8_t class_of[256], uint32_t nclass, uint32_t pass)
+int skh_text_count(skh_ctx* cx, skh_text* t, const uint8_t class_of[256], uint32_t nclass, uint32_t pass)
 {
     if (!t || !class_of) return fail(SKH_EINVAL, "NULL argument");
+    if (t->ctx != cx) return fail(SKH_EINVAL, "the text block belongs to another context");
     if (pass >= SKH_TAB_MAX_PASSES) return fail(SKH_EINVAL, "pass out of range");
     if (nclass < 1 || nclass > SKH_MAX_CLASSES) return fail(SKH_EINVAL, "nclass out of range");
     t->nclass[pass] = nclass;
@@ -481,27 +494,30 @@ int skh_text_count(skh_ctx*, skh_text* t, const uint8_t class_of[256], uint32_t 
     if (t->nrec) ora_batch_count(t->seq.data(), t->offs.data(), t->nrec, class_of, nclass, t->counts[pass].data());
     return SKH_OK;
 }
-int skh_text_letters(skh_ctx*, skh_text* t)
+int skh_text_letters(skh_ctx* cx, skh_text* t)
 {
     if (!t) return fail(SKH_EINVAL, "NULL argument");
+    if (t->ctx != cx) return fail(SKH_EINVAL, "the text block belongs to another context");
     t->letters.assign((t->nrec ? t->nrec : 1) * 8, 0);
     for (uint64_t r = 0; r < t->nrec; r++)
         for (uint64_t i = t->offs[r]; i < t->offs[r + 1]; i++) t->letters[r * 8 + (t->seq[i] >> 5)] |= 1u << (t->seq[i] & 31);
     t->letters_ready = true;
     return SKH_OK;
 }
-int skh_text_stats(skh_ctx*, skh_text* t, const uint8_t is_gap[256], skh_stats_partial* inout)
+int skh_text_stats(skh_ctx* cx, skh_text* t, const uint8_t is_gap[256], skh_stats_partial* inout)
 {
     if (!t || !is_gap || !inout) return fail(SKH_EINVAL, "NULL argument");
+    if (t->ctx != cx) return fail(SKH_EINVAL, "the text block belongs to another context");
     if (t->nrec == 0) return SKH_OK;
     skh_stats_partial p;
     stats_of(t->seq.data(), t->offs.data(), t->nrec, is_gap, &p);
     skh_stats_merge(inout, &p);
     return SKH_OK;
 }
-int skh_text_remove_gaps(skh_ctx*, skh_text* t, const uint8_t is_gap[256])
+int skh_text_remove_gaps(skh_ctx* cx, skh_text* t, const uint8_t is_gap[256])
 {
     if (!t || !is_gap) return fail(SKH_EINVAL, "NULL argument");
+    if (t->ctx != cx) return fail(SKH_EINVAL, "the text block belongs to another context");
     if (t->transformed) return fail(SKH_EINVAL, "block was already transformed");
     if (t->gaps_removed) return fail(SKH_EINVAL, "gaps were already removed from this block");
     if (t->nrec == 0) return SKH_OK;
@@ -523,12 +539,14 @@ int skh_text_remove_gaps(skh_ctx*, skh_text* t, const uint8_t is_gap[256])
     return SKH_OK;
 }
 
-int skh_text_subseq(skh_ctx*, skh_text* t, const skh_slice* slices, uint64_t n, int64_t start, int64_t end, int minus,
+int skh_text_subseq(skh_ctx* cx, skh_text* t, const skh_slice* slices, uint64_t n, int64_t start, int64_t end, int minus,
                     const uint8_t* lut, const uint8_t* names, uint64_t names_bytes, const uint64_t* name_pos,
                     const uint32_t* name_len)
 {
     if (!t) return fail(SKH_EINVAL, "NULL argument");
+    if (t->ctx != cx) return fail(SKH_EINVAL, "the text block belongs to another context");
     if (t->transformed) return fail(SKH_EINVAL, "block was already transformed");
+    if (t->gaps_removed) return fail(SKH_EINVAL, "gaps were removed from this block: cut subsequences before skh_text_remove_gaps");
     if (!slices) n = t->nrec;
     if (!names && slices) return fail(SKH_EINVAL, "a slice list needs names for its records");
     if (names && (!name_pos || !name_len)) return fail(SKH_EINVAL, "NULL name table");
@@ -566,13 +584,13 @@ int skh_text_subseq(skh_ctx*, skh_text* t, const skh_slice* slices, uint64_t n, 
     return SKH_OK;
 }
 
-int skh_text_format_seq_submit(skh_ctx*, skh_text* t, const skh_seq_format* f)
+int skh_text_format_seq_submit(skh_ctx* cx, skh_text* t, const skh_seq_format* f)
 {
     if (!t || !f) return fail(SKH_EINVAL, "NULL argument");
+    if (t->ctx != cx) return fail(SKH_EINVAL, "the text block belongs to another context");
     t->out_pending = 0;
     t->out.clear();
     if (t->nrec == 0) return SKH_OK;
-    if (f->print_qual && !t->fastq) return fail(SKH_EINVAL, "quality requested for a FASTA block");
     const uint64_t* fo = t->filter_offs.empty() ? t->offs.data() : t->filter_offs.data();
     for (uint64_t r = 0; r < t->nrec; r++) {
         const uint64_t len = t->offs[r + 1] - t->offs[r], flen = fo[r + 1] - fo[r];
@@ -589,7 +607,7 @@ int skh_text_format_seq_submit(skh_ctx*, skh_text* t, const skh_seq_format* f)
         if (f->print_seq) { put_wrapped(t->out, t->seq.data() + t->offs[r], len, (uint32_t)f->line_width); t->out.push_back('\n'); }
         if (f->print_qual && !as_fasta) {
             if (f->plus_line) { t->out.push_back('+'); t->out.push_back('\n'); }
-            put_wrapped(t->out, t->qual.data() + t->offs[r], len, (uint32_t)f->line_width);
+            if (t->fastq) put_wrapped(t->out, t->qual.data() + t->offs[r], len, (uint32_t)f->line_width);
             t->out.push_back('\n');
         }
     }
@@ -597,9 +615,10 @@ int skh_text_format_seq_submit(skh_ctx*, skh_text* t, const skh_seq_format* f)
     return SKH_OK;
 }
 
-int skh_text_format_tab_submit(skh_ctx*, skh_text* t, const skh_tab_format* f)
+int skh_text_format_tab_submit(skh_ctx* cx, skh_text* t, const skh_tab_format* f)
 {
     if (!t || !f) return fail(SKH_EINVAL, "NULL argument");
+    if (t->ctx != cx) return fail(SKH_EINVAL, "the text block belongs to another context");
     t->out_pending = 0;
     t->out.clear();
     if (t->nrec == 0) return SKH_OK;
@@ -647,9 +666,10 @@ int skh_text_format_tab_submit(skh_ctx*, skh_text* t, const skh_tab_format* f)
     return SKH_OK;
 }
 
-int skh_text_output_wait(skh_ctx*, skh_text* t, const uint8_t** out, uint64_t* out_bytes)
+int skh_text_output_wait(skh_ctx* cx, skh_text* t, const uint8_t** out, uint64_t* out_bytes)
 {
     if (!t || !out || !out_bytes) return fail(SKH_EINVAL, "NULL argument");
+    if (t->ctx != cx) return fail(SKH_EINVAL, "the text block belongs to another context");
     *out = t->out_pending ? t->out.data() : nullptr;
     *out_bytes = t->out_pending;
     t->out_pending = 0;
@@ -664,6 +684,39 @@ int skh_text_format_tab(skh_ctx* c, skh_text* t, const skh_tab_format* f, const 
 {
     const int rc = skh_text_format_tab_submit(c, t, f);
     return rc ? rc : skh_text_output_wait(c, t, out, n);
+}
+
+// ---------------------------------------------------------------- several "GPUs"
+
+}  // extern "C"
+
+struct skh_comm { std::vector<skh_ctx*> ctx; };
+
+extern "C" {
+
+int skh_comm_init_all(skh_ctx* const* ctxs, int n, skh_comm** out)
+{
+    if (!ctxs || !out || n < 1) return fail(SKH_EINVAL, "skh_comm_init_all: bad argument");
+    *out = new skh_comm;
+    (*out)->ctx.assign(ctxs, ctxs + n);
+    return SKH_OK;
+}
+int skh_comm_unique_id(uint8_t id[SKH_COMM_ID_BYTES]) { memset(id, 7, SKH_COMM_ID_BYTES); return SKH_OK; }
+int skh_comm_init_rank(skh_ctx* ctx, const uint8_t*, int nranks, int rank, skh_comm** out)
+{
+    if (!ctx || !out || nranks != 1 || rank != 0) return fail(SKH_EINVAL, "the CPU stub has no other processes to talk to");
+    return skh_comm_init_all(&ctx, 1, out);
+}
+void skh_comm_destroy(skh_comm* c) { delete c; }
+int skh_comm_local_ranks(const skh_comm* c) { return c ? (int)c->ctx.size() : 0; }
+int skh_stats_allreduce(skh_comm* c, skh_stats_partial* partials)
+{
+    if (!c || !partials) return fail(SKH_EINVAL, "NULL argument");
+    skh_stats_partial tot;
+    skh_stats_init(&tot);
+    for (size_t i = 0; i < c->ctx.size(); i++) skh_stats_merge(&tot, &partials[i]);
+    for (size_t i = 0; i < c->ctx.size(); i++) partials[i] = tot;
+    return SKH_OK;
 }
 
 }  // extern "C"

@@ -116,3 +116,40 @@ def test_host_parse_mode(san, oracle_cli, which):
             want = run_cli(oracle_cli, argv + [f])
             got = clean(run_cli(san[which], argv + ["--host-parse", "--batch-records", "100"] + [f]))
             assert got[0] == 0 and got[1] == want[1]
+
+
+@pytest.mark.parametrize("which", ["asan", "tsan"])
+def test_blocks_dealt_to_several_devices(san, oracle_cli, which, tmp_path, monkeypatch):
+    # --gpus N: the blocks of a file go round N contexts; output order, tails and the merged stats
+    # must not depend on N (the stub has as many "devices" as SKH_STUB_DEVICES says)
+    monkeypatch.setenv("SKH_STUB_DEVICES", "8")
+    f = str(tmp_path / "late.fq")
+    wrapped_fastq(f, four_line_head=1800)
+    for argv, files in ((["seq", "-r", "-p"], ["hairpin.fa.gz"]), (["seq"], ["reads_1.fq.gz", "contigs.fa"]),
+                        (["fx2tab", "-n", "-l", "-g", "-B", "AGCT"], ["reads_2.fq.gz"]),
+                        (["stats", "-a"], ["hairpin.fa.gz", "mature.fa.gz", "Illimina1.8.fq.gz", "contigs.fa"]),
+                        (["stats", "-T"], [f]), (["seq", "-r", "-p", "-w", "0"], [f]),
+                        (["convert", "--to", "Illumina-1.5+"], ["reads_1.fq.gz"]), (["subseq", "-r", "2:-2"], ["mature.fa.gz"])):
+        want = run_cli(oracle_cli, argv + files)
+        for dev in (["--gpus", "2"], ["--gpus", "5"], ["--devices", "3,3,1"]):
+            got = clean(run_cli(san[which], argv + dev + ["--batch-bytes", "16384"] + files))
+            assert got[0] == want[0] == 0 and got[1] == want[1], (argv, dev, got[2][-500:])
+    rc, _, err = run_cli(san["asan"], ["stats", "--gpus", "9", "contigs.fa"])
+    assert rc == 255 and b"[ERRO] device ordinal out of range" in err
+
+
+def test_fasta_after_fastq_keeps_the_fastq_layout(san, oracle_cli):
+    # seq.go:140-149: the layout is decided once; records of a later FASTA file get "+" and an empty quality
+    want = run_cli(oracle_cli, ["seq", "reads_1.fq.gz", "contigs.fa"])
+    assert want[1].endswith(b"@length=9\nAAAAAAAAA\n+\n\n")
+    for mode in ([], ["--host-parse"]):
+        got = clean(run_cli(san["asan"], ["seq"] + mode + ["reads_1.fq.gz", "contigs.fa"]))
+        assert got[0] == 0 and got[1] == want[1]
+
+
+def test_stats_type_follows_seq_type_flag(san, oracle_cli):
+    # stat.go:87,128-134: -t goes to the reader, the type column shows it
+    for mode in ([], ["--host-parse"]):
+        got = clean(run_cli(san["asan"], ["stats", "-T", "-t", "protein"] + mode + ["contigs.fa"]))
+        want = run_cli(oracle_cli, ["stats", "-T", "-t", "protein", "contigs.fa"])
+        assert got[1] == want[1] and b"\tProtein\t" in got[1]

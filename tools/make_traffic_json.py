@@ -2,7 +2,7 @@
 """Builds profiles/<tag>_hbm_traffic.json from two rocprofv3 --pmc passes over the same bench
 command (one with TCC_EA0_RDREQ-derived FETCH_SIZE, one with WRITE_SIZE): per-kernel averages per
 launch.  usage: make_traffic_json.py <fetch_dir> <write_dir> <out.json> <nrec> <read_len>"""
-import collections, csv, glob, json, os, sys
+import collections, csv, glob, hashlib, json, os, sys
 
 def averages(d, counter):
     agg = collections.defaultdict(list)
@@ -29,7 +29,11 @@ doc = {"note": "rocprofv3 --pmc, two separate passes (FETCH_SIZE, then WRITE_SIZ
                "--warmup 1` on MI355X, kernel filter skh; per-launch averages in KB as reported.  gfx950 correction: "
                "FETCH_SIZE counts 128-B read requests as 64 B for wide coalesced streams, so bytes_read = 2 * "
                "FETCH_SIZE * 1024; WRITE_SIZE * 1024 is exact.",
-       "workload": "%d x %d bp, one plane per launch" % (nrec, L), "kernels": kernels}
+       "workload": "%d x %d bp, one plane per launch" % (nrec, L),
+       # bench.py reports these figures only while kernels.hip is the file they were measured on
+       "kernels_sha16": hashlib.sha256(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "seqkit_amd", "csrc",
+                                                         "kernels.hip"), "rb").read()).hexdigest()[:16],
+       "kernels": kernels}
 with open(out, "w") as fh:
     json.dump(doc, fh, indent=1)
 print(json.dumps(doc, indent=1))
