@@ -269,6 +269,7 @@ class Bench:
     def time_ms(self, fn, reps=5, warm=2):
         """Average duration of fn() over `reps` launches, HIP events on the launch stream."""
         torch = self.torch
+        torch.cuda.synchronize()         # the operands were made on torch's own stream
         for _ in range(warm):
             fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -410,6 +410,12 @@ int skh_text_map_quality(skh_ctx *ctx, skh_text *t, const uint8_t lut[256]);
 /* name_pos / name_len of records [first, first+count) copied to host memory; the names
  * themselves lie in skh_text_buffer(). */
 int skh_text_names(skh_ctx *ctx, skh_text *t, uint64_t first, uint64_t count, uint64_t *pos, uint32_t *len);
+/* Replaces the name spans of records [first, first+count) by spans the caller picked inside
+ * skh_text_buffer() (inside the parsed text): how a caller prints record IDs cut out by a rule of its
+ * own, e.g. the capture group of --id-regexp (seqkit/cmd/root.go:68, helper.go:125-135; handed to the
+ * reader at seq.go:115, fx2tab.go:96), with only_id off. */
+int skh_text_set_names(skh_ctx *ctx, skh_text *t, uint64_t first, uint64_t count, const uint64_t *pos,
+                       const uint32_t *len);
 /* skh_subseq_dev on the block: afterwards the block holds the n slices as its records, and
  * every later call on it (format, count, stats, validate) sees those.  `slices` is host memory
  * (NULL = region mode with start / end / minus, n ignored).  names == NULL keeps the names of

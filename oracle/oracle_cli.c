@@ -87,6 +87,15 @@ int main(int argc, char **argv)
         if (is_flag(a, "-w", "--line-width")) { so.line_width = atoi(NEXT()); continue; }
         if (is_flag(a, "-j", "--threads")) { (void)NEXT(); continue; }
         if (is_flag(a, NULL, "--quiet")) { so.quiet = 1; continue; }
+        if (is_flag(a, NULL, "--id-ncbi")) { ora_set_id_regexp("\\|([^\\|]+)\\| "); continue; }          /* helper.go:129-131 */
+        if (is_flag(a, NULL, "--id-regexp")) {
+            const char *v = value_of(&i, argc, argv);
+            if (!v || ora_set_id_regexp(v) != 0) {
+                fprintf(stderr, "[ERRO] regular expression must contain \"(\" and \")\" to capture matched ID. default: `^([^\\s]+)\\s?`\n");
+                return 255;
+            }
+            continue;
+        }
         if (is_flag(a, NULL, "--alphabet-guess-seq-length")) {
             size_t v = (size_t)atoll(NEXT()); so.guess_len = fo.guess_len = to.guess_len = uo.guess_len = v; continue;
         }

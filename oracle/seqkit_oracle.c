@@ -11,6 +11,7 @@
 
 #include <ctype.h>
 #include <math.h>
+#include <regex.h>
 #include <stdlib.h>
 #include <string.h>
 #include <strings.h>
@@ -353,6 +354,60 @@ static size_t id_length(const uint8_t *name, size_t n)
     return i == 0 ? n : i;   /* regexp does not match -> whole head */
 }
 
+/* a custom ID expression (ora_set_id_regexp) */
+static regex_t g_id_re;
+static int g_id_re_set = 0;
+
+int ora_set_id_regexp(const char *go)
+{
+    if (g_id_re_set) { regfree(&g_id_re); g_id_re_set = 0; }
+    if (!go || !strcmp(go, "^([^\\s]+)\\s?")) return 0;
+    if (!strchr(go, '(') || !strchr(go, ')')) return -1;
+    /* Perl classes -> POSIX: outside brackets \s = [[:space:]] ..., inside brackets \s = [:space:] ...,
+     * any other escaped byte inside brackets stands for itself */
+    size_t n = strlen(go);
+    char *ere = (char *)malloc(16 * n + 16), *w = ere;
+    int in_br = 0;
+    for (size_t i = 0; i < n; i++) {
+        char c = go[i];
+        if (c == '\\' && i + 1 < n) {
+            char d = go[++i];
+            const char *cls = d == 's' || d == 'S' ? "[:space:]" : d == 'd' || d == 'D' ? "[:digit:]"
+                            : d == 'w' || d == 'W' ? "[:alnum:]_" : NULL;
+            if (cls) {
+                const int neg = d == 'S' || d == 'D' || d == 'W';
+                if (in_br) w += sprintf(w, "%s", cls);            /* (negated classes inside brackets: not needed here) */
+                else w += sprintf(w, "[%s%s]", neg ? "^" : "", cls);
+            } else if (in_br) *w++ = d;
+            else { *w++ = '\\'; *w++ = d; }
+            continue;
+        }
+        if (!in_br && c == '[') { in_br = 1; *w++ = c; if (i + 1 < n && go[i + 1] == '^') *w++ = go[++i]; continue; }
+        if (in_br && c == ']') in_br = 0;
+        *w++ = c;
+    }
+    *w = 0;
+    const int rc = regcomp(&g_id_re, ere, REG_EXTENDED);
+    free(ere);
+    if (rc != 0) return -1;
+    g_id_re_set = 1;
+    return 0;
+}
+
+/* ID of a head line: where it starts and how long it is */
+static const uint8_t *id_of(uint8_t *name, size_t n, size_t *len)
+{
+    if (!g_id_re_set) { *len = id_length(name, n); return name; }
+    regmatch_t m[2];
+    const uint8_t saved = name[n];
+    name[n] = 0;                                   /* the reader's name buffer has room for it */
+    const int hit = regexec(&g_id_re, (const char *)name, 2, m, 0) == 0 && m[1].rm_so >= 0;
+    name[n] = saved;
+    if (!hit) { *len = n; return name; }
+    *len = (size_t)(m[1].rm_eo - m[1].rm_so);
+    return name + m[1].rm_so;
+}
+
 int ora_reader_next(ora_reader *r, ora_record *rec)
 {
     /* skip blank lines between records */
@@ -398,7 +453,7 @@ int ora_reader_next(ora_reader *r, ora_record *rec)
     if (r->alphabet < 0)
         r->alphabet = r->forced_alphabet >= 0 ? r->forced_alphabet
                                               : ora_guess_alphabet(r->seq, sl, r->guess_threshold);
-    rec->name = r->name; rec->name_len = nl; rec->id_len = id_length(r->name, nl);
+    rec->name = r->name; rec->name_len = nl; rec->id = id_of(r->name, nl, &rec->id_len);
     rec->seq = r->seq; rec->seq_len = sl;
     rec->qual = r->qual; rec->qual_len = ql;
     return 1;
@@ -458,7 +513,7 @@ int ora_cmd_seq(const ora_seq_opts *o, int nfiles, const char **files, FILE *out
                 if (bad >= 0) {
                     fflush(out);
                     fprintf(err, "[ERRO] error when parsing seq: %.*s (invalid %s letter: %c)\n", (int)rec.id_len,
-                            (const char *)rec.name, ora_alphabet_name(vab), rec.seq[bad]);
+                            (const char *)rec.id, ora_alphabet_name(vab), rec.seq[bad]);
                     ora_reader_close(r); free(wrapbuf); return 255;
                 }
             }
@@ -479,8 +534,9 @@ int ora_cmd_seq(const ora_seq_opts *o, int nfiles, const char **files, FILE *out
             }
             if (pn) {
                 size_t hl = o->only_id ? rec.id_len : rec.name_len;
+                const uint8_t *hp = o->only_id ? rec.id : rec.name;
                 if (ps) fputc(is_fastq ? '@' : '>', out);
-                fwrite(rec.name, 1, hl, out); fputc('\n', out);
+                fwrite(hp, 1, hl, out); fputc('\n', out);
             }
             int ab = ora_reader_alphabet(r);
             if (o->reverse) ora_reverse_inplace(rec.seq, rec.qual_len ? rec.qual : NULL, rec.seq_len);
@@ -559,7 +615,7 @@ int ora_cmd_fx2tab(const ora_fx2tab_opts *o, int nfiles, const char **files, FIL
         if (!r) { fprintf(err, "[ERRO] open %s: no such file or directory\n", files[f]); return 255; }
         ora_record rec; int rc;
         while ((rc = ora_reader_next(r, &rec)) == 1) {
-            fwrite(rec.name, 1, o->only_id ? rec.id_len : rec.name_len, out);
+            fwrite(o->only_id ? rec.id : rec.name, 1, o->only_id ? rec.id_len : rec.name_len, out);
             fputc('\t', out);
             if (!o->only_name) fwrite(rec.seq, 1, rec.seq_len, out);
             fputc('\t', out);
@@ -974,7 +1030,7 @@ int ora_cmd_subseq(const ora_subseq_opts *o, int nfiles, const char **files, FIL
                 for (long i = 0; i < nf; i++) {
                     const feature *ft = &fs[i];
                     if (strcmp(ft->type, types[t]) != 0) continue;
-                    if (strlen(ft->chr) != rec.id_len || strncasecmp(ft->chr, (const char *)rec.name, rec.id_len) != 0) continue;
+                    if (strlen(ft->chr) != rec.id_len || strncasecmp(ft->chr, (const char *)rec.id, rec.id_len) != 0) continue;
                     int64_t s = ft->start, e = ft->end;                          /* subseq.go:379-420, 471-512 */
                     const int minus = ft->strand == '-';
                     if (minus) {
@@ -1006,7 +1062,7 @@ int ora_cmd_subseq(const ora_subseq_opts *o, int nfiles, const char **files, FIL
                     }
                     size_t need = rec.id_len + strlen(ft->label) + 160;
                     if (need > namecap) { namecap = need; name = (char *)realloc(name, namecap); }
-                    int nl = snprintf(name, namecap, "%.*s_%lld-%lld:%c%s %s", (int)rec.id_len, (const char *)rec.name,
+                    int nl = snprintf(name, namecap, "%.*s_%lld-%lld:%c%s %s", (int)rec.id_len, (const char *)rec.id,
                                       (long long)ft->start, (long long)ft->end, ft->strand ? ft->strand : '.', flank, ft->label);
                     write_fasta(out, name, (size_t)nl, sub, m, width, &wrapbuf, &wrapcap);
                 }

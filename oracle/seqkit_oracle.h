@@ -95,12 +95,21 @@ void ora_batch_stats(const uint8_t *seq, const uint64_t *offs, uint64_t nrec,
 /* ---- FASTA/Q reader (bio/seqio/fastx restated; plain or gzip input, "-" = stdin) ---- */
 typedef struct ora_record {
     uint8_t *name; size_t name_len;   /* head line without '>'/'@' */
-    size_t id_len;                    /* ID = name[0..id_len) (default id regexp) */
+    size_t id_len;                    /* ID = id[0..id_len): capture group 1 of the ID expression in the name */
+    const uint8_t *id;                /* (the default expression makes it a prefix of the name) */
     uint8_t *seq;  size_t seq_len;
     uint8_t *qual; size_t qual_len;   /* 0 for FASTA */
 } ora_record;
 
 typedef struct ora_reader ora_reader;
+/* --id-regexp / --id-ncbi (seqkit/cmd/root.go:68-69, helper.go:125-135; handed to fastx.NewReader at
+ * seq.go:115, fx2tab.go:96, stat.go:87): the ID of every record read afterwards is capture group 1 of the
+ * expression matched against the head line, the whole head line where it does not match.  NULL or the
+ * default `^([^\s]+)\s?` restores the built-in rule.  The Go expression is handed to POSIX regcomp
+ * after its Perl classes (\s \S \d \D \w \W, also inside brackets) have been spelled out; pinned by
+ * doc/docs/usage.md:345-348, otherwise parity unpinned.  Returns 0, or -1 when the expression does
+ * not compile or has no group. */
+int ora_set_id_regexp(const char *go_regexp);
 ora_reader *ora_reader_open(const char *path, int forced_alphabet /* -1 = guess */,
                             size_t guess_threshold);
 /* 1 = record returned (valid until next call), 0 = EOF, <0 = parse error */

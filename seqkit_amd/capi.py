@@ -101,6 +101,7 @@ SYMBOLS = {
     "skh_subseq_dev": (C.c_int, [vp, vp, vp, vp, C.c_uint64, C.c_uint64, vp, C.c_uint64, C.c_int64, C.c_int64, C.c_int,
                                  u8p, vp, vp, C.c_uint64, vp, vp, C.c_uint64, vp, vp]),
     "skh_text_names": (C.c_int, [vp, vp, C.c_uint64, C.c_uint64, u64p, C.POINTER(C.c_uint32)]),
+    "skh_text_set_names": (C.c_int, [vp, vp, C.c_uint64, C.c_uint64, u64p, C.POINTER(C.c_uint32)]),
     "skh_text_subseq": (C.c_int, [vp, vp, C.POINTER(Slice), C.c_uint64, C.c_int64, C.c_int64, C.c_int, u8p, u8p,
                                   C.c_uint64, u64p, C.POINTER(C.c_uint32)]),
     "skh_text_alloc": (C.c_int, [vp, C.c_uint64, C.POINTER(vp)]),

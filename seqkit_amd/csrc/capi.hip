@@ -16,6 +16,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "kernels.h"
 #include "ctx.h"
@@ -1339,6 +1340,27 @@ int skh_text_names(skh_ctx* ctx, skh_text* t, uint64_t first, uint64_t count, ui
     HIP_TRY(hipStreamSynchronize(t->stream));
     if (t->v_text == t->d_text && t->text_off)             // positions in skh_text_buffer()
         for (uint64_t i = 0; i < count; i++) pos[i] += t->text_off;
+    return SKH_OK;
+}
+
+int skh_text_set_names(skh_ctx* ctx, skh_text* t, uint64_t first, uint64_t count, const uint64_t* pos, const uint32_t* len)
+{
+    if (!ctx || !t || ((!pos || !len) && count)) return fail(SKH_EINVAL, "NULL argument");
+    if (t->ctx != ctx) return fail(SKH_EINVAL, "the text block belongs to another context");
+    if (first + count > t->nrec) return fail(SKH_EINVAL, "record range beyond the block");
+    if (t->v_text != t->d_text) return fail(SKH_EINVAL, "the block's names no longer lie in its text buffer");
+    if (count == 0) return SKH_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    // positions come in skh_text_buffer() coordinates; the device copy of the text starts at text_off
+    std::vector<uint64_t> p(count);
+    for (uint64_t i = 0; i < count; i++) {
+        if (pos[i] < t->text_off || pos[i] + len[i] > t->text_off + t->text_bytes)
+            return fail(SKH_EINVAL, "a name span lies outside the parsed text");
+        p[i] = pos[i] - t->text_off;
+    }
+    HIP_TRY(hipMemcpyAsync(t->d_npos + first, p.data(), count * 8, hipMemcpyHostToDevice, t->stream));
+    HIP_TRY(hipMemcpyAsync(t->d_nlen + first, len, count * 4, hipMemcpyHostToDevice, t->stream));
+    HIP_TRY(hipStreamSynchronize(t->stream));
     return SKH_OK;
 }
 

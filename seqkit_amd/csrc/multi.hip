@@ -14,9 +14,11 @@
 #include "seqkit_hip.h"
 
 #include <dlfcn.h>
+#include <unistd.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <cstdio>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -70,6 +72,15 @@ int need_rccl()
     const char* why = dlerror();
     return skh::set_error(SKH_ENODEV, "RCCL (librccl.so) could not be loaded: %s", why ? why : "missing symbols");
 }
+
+// RCCL announces itself on standard output when a communicator is made ("RCCL version : ...").  The
+// standard output of a process that uses this library is its data (the driver writes records there),
+// so file descriptor 1 points at standard error while RCCL initialises.
+struct StdoutToStderr {
+    int saved;
+    StdoutToStderr() { fflush(stdout); saved = dup(1); if (saved >= 0) (void)dup2(2, 1); }
+    ~StdoutToStderr() { fflush(stdout); if (saved >= 0) { (void)dup2(saved, 1); close(saved); } }
+};
 
 int rccl_fail(ncclResult_t r, const char* what) { return skh::set_error(SKH_EHIP, "%s: %s", what, g_rccl.GetErrorString(r)); }
 int hip_fail(hipError_t e, const char* what) { return skh::set_error(SKH_EHIP, "%s: %s", what, hipGetErrorString(e)); }
@@ -134,7 +145,10 @@ int skh_comm_unique_id(uint8_t id[SKH_COMM_ID_BYTES])
     if (!id) return skh::set_error(SKH_EINVAL, "NULL argument");
     if (int rc = need_rccl()) return rc;
     ncclUniqueId u;
-    RCCL_TRY(g_rccl.GetUniqueId(&u));
+    {
+        StdoutToStderr quiet;
+        RCCL_TRY(g_rccl.GetUniqueId(&u));
+    }
     memcpy(id, u.internal, SKH_COMM_ID_BYTES);
     return SKH_OK;
 }
@@ -180,6 +194,7 @@ int skh_comm_init_all(skh_ctx* const* ctxs, int n, skh_comm** out)
     c->device = devices;
     int rc = comm_buffers(c);
     if (rc == SKH_OK) {
+        StdoutToStderr quiet;
         const ncclResult_t r = g_rccl.CommInitAll(c->comm.data(), c->nlocal, c->device.data());
         if (r != ncclSuccess) rc = rccl_fail(r, "ncclCommInitAll");
     }
@@ -201,6 +216,7 @@ int skh_comm_init_rank(skh_ctx* ctx, const uint8_t id[SKH_COMM_ID_BYTES], int nr
     if (rc == SKH_OK) {
         ncclUniqueId u;
         memcpy(u.internal, id, SKH_COMM_ID_BYTES);
+        StdoutToStderr quiet;
         const ncclResult_t r = g_rccl.CommInitRank(&c->comm[0], nranks, u, rank);     // the device is current (comm_buffers)
         if (r != ncclSuccess) rc = rccl_fail(r, "ncclCommInitRank");
     }

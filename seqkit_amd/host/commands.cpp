@@ -806,6 +806,24 @@ private:
 void drop_cached_blocks() { BlockPipe::drop_cache(); }
 namespace {
 
+// Record IDs by a rule other than the default one: the name spans of the block are replaced by the ID
+// spans (the formatter then prints "names" that are the IDs).  The head lines are on the host already
+// (the block's text buffer); the expression runs here, record by record.
+int custom_ids_as_names(const GlobalOpts& g, skh_text* t, uint64_t nrec, std::vector<uint64_t>& npos, std::vector<uint32_t>& nlen)
+{
+    skh_ctx* ctx = skh_text_ctx(t);
+    npos.resize(nrec); nlen.resize(nrec);
+    if (skh_text_names(ctx, t, 0, nrec, npos.data(), nlen.data()) != SKH_OK) return fatal(skh_last_error());
+    const uint8_t* text = skh_text_buffer(t);
+    for (uint64_t r = 0; r < nrec; r++) {
+        uint32_t off = 0, len = 0;
+        id_span(g, text + npos[r], nlen[r], &off, &len);
+        npos[r] += off; nlen[r] = len;
+    }
+    if (skh_text_set_names(ctx, t, 0, nrec, npos.data(), nlen.data()) != SKH_OK) return fatal(skh_last_error());
+    return 0;
+}
+
 // alphabet of a file as the reference's reader guesses it: from the first record
 int first_record_alphabet(skh_ctx* ctx, skh_text* t, const GlobalOpts& g, int forced, std::string& err)
 {
@@ -823,7 +841,8 @@ int first_record_alphabet(skh_ctx* ctx, skh_text* t, const GlobalOpts& g, int fo
 int seq_text_path(const GlobalOpts& g, const SeqOpts& o, const std::vector<std::string>& files, const std::vector<skh_ctx*>& ctxs, Sink& out)
 {
     bool is_fastq = false, check_type = true;        // seq.go:105-106: decided once, by the first printed record
-    std::vector<uint64_t> offs;
+    std::vector<uint64_t> offs, id_pos;
+    std::vector<uint32_t> id_len;
     for (const std::string& file : files) {
         bool warn_once = true;                       // seq.go:118: one "already RNA / DNA" warning per file
         BlockPipe tb(ctxs, file, g.text_block_bytes);
@@ -867,10 +886,9 @@ int seq_text_path(const GlobalOpts& g, const SeqOpts& o, const std::vector<std::
                     uint64_t npos = 0; uint32_t nlen = 0;
                     if (skh_text_name(ctx, t, vr.record, &npos, &nlen) != SKH_OK) return fatal(skh_last_error());
                     const uint8_t* name = skh_text_buffer(t) + npos;
-                    uint32_t idl = 0;
-                    while (idl < nlen && !(name[idl] == ' ' || (name[idl] >= '\t' && name[idl] <= '\r'))) idl++;
-                    if (idl == 0) idl = nlen;
-                    pending_error = "error when parsing seq: " + std::string((const char*)name, idl) + " (invalid " +
+                    uint32_t ido = 0, idl = 0;
+                    id_span(g, name, nlen, &ido, &idl);
+                    pending_error = "error when parsing seq: " + std::string((const char*)name + ido, idl) + " (invalid " +
                                     alphabet_name(ab) + " letter: " + std::string(1, (char)vr.letter) + ")";
                     if (skh_text_truncate(ctx, t, vr.record) != SKH_OK) return fatal(skh_last_error());
                     res.nrec = vr.record;
@@ -962,6 +980,10 @@ int seq_text_path(const GlobalOpts& g, const SeqOpts& o, const std::vector<std::
                 // (a FASTA file after a FASTQ one keeps the FASTQ layout: "+" and an empty quality line,
                 // seq.go:140-149,258-276; the formatter prints that for a block without a quality plane)
                 f.only_id = o.only_id;
+                if (o.only_id && g.id_re && f.print_name) {
+                    if (int rc = custom_ids_as_names(g, t, res.nrec, id_pos, id_len)) return rc;
+                    f.only_id = 0;
+                }
                 f.mark = is_fastq ? '@' : '>';
                 {
                     PhaseTimer pt(3);
@@ -1172,6 +1194,8 @@ int cmd_fx2tab(const GlobalOpts& g, const Fx2tabOpts& o, const std::vector<std::
         tf.only_id = o.only_id;
     }
     if (device_rows) {
+        std::vector<uint64_t> id_pos;
+        std::vector<uint32_t> id_len;
         for (const std::string& file : files) {
             BlockPipe tb(ctx.all, file, g.text_block_bytes);
             if (!tb.ok()) return fatal(tb.error());
@@ -1206,6 +1230,11 @@ int cmd_fx2tab(const GlobalOpts& g, const Fx2tabOpts& o, const std::vector<std::
                     if (skh_text_letters(skh_text_ctx(t), t) != SKH_OK) return fatal(skh_last_error());
                 }
                 tf.alphabet = o.alphabet_col ? 1 : 0;
+                tf.only_id = o.only_id;
+                if (o.only_id && g.id_re) {
+                    if (int rc = custom_ids_as_names(g, t, res.nrec, id_pos, id_len)) return rc;
+                    tf.only_id = 0;
+                }
                 tf.print_seq = !o.only_name;
                 tf.print_qual = !o.only_name && tb.is_fastq();
                 {
@@ -1707,10 +1736,9 @@ int cmd_subseq(const GlobalOpts& g, const SubseqOpts& o, const std::vector<std::
                 const uint8_t* text = skh_text_buffer(t);
                 for (uint64_t r = 0; r < res.nrec; r++) {
                     const uint8_t* name = text + npos[r];
-                    uint32_t idl = 0;
-                    while (idl < nlen[r] && !(name[idl] == ' ' || (name[idl] >= '\t' && name[idl] <= '\r'))) idl++;
-                    if (idl == 0) idl = nlen[r];
-                    const std::string id((const char*)name, idl), key = lower(id);
+                    uint32_t ido = 0, idl = 0;
+                    id_span(g, name, nlen[r], &ido, &idl);
+                    const std::string id((const char*)name + ido, idl), key = lower(id);
                     auto it = std::lower_bound(by_chr.begin(), by_chr.end(), key, [](const auto& kv, const std::string& k) { return kv.first < k; });
                     if (it == by_chr.end() || it->first != key) continue;
                     const long long len = (long long)(offs[r + 1] - offs[r]);

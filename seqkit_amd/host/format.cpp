@@ -115,4 +115,22 @@ void write_wrapped(Sink& out, const uint8_t* s, size_t n, int width)
     }
 }
 
+void id_span(const GlobalOpts& g, const uint8_t* name, uint32_t n, uint32_t* off, uint32_t* len)
+{
+    if (!g.id_re) {
+        // `^([^\s]+)\s?`: up to the first white space; no match (empty, or starts with white space): the whole line
+        uint32_t i = 0;
+        while (i < n && !(name[i] == ' ' || (name[i] >= '\t' && name[i] <= '\r'))) i++;
+        *off = 0; *len = i == 0 ? n : i;
+        return;
+    }
+    std::cmatch m;
+    const char* b = reinterpret_cast<const char*>(name);
+    if (std::regex_search(b, b + n, m, *g.id_re) && m.size() > 1 && m[1].matched) {
+        *off = (uint32_t)(m[1].first - b); *len = (uint32_t)m[1].length();
+    } else {
+        *off = 0; *len = n;
+    }
+}
+
 }  // namespace host

@@ -7,6 +7,8 @@
 #pragma once
 #include <cstdint>
 #include <cstdio>
+#include <memory>
+#include <regex>
 #include <string>
 #include <vector>
 
@@ -101,6 +103,11 @@ struct GlobalOpts {
                                   // blocks of a file are dealt to in turn (always at least one entry)
     uint64_t batch_bytes = 256ull << 20, batch_records = 4ull << 20;
     uint64_t text_block_bytes = 32ull << 20;   // text path: file bytes per block (--batch-bytes overrides)
+    // --id-regexp / --id-ncbi (root.go:68-69, helper.go:125-135): the record ID is capture group 1 of the
+    // expression matched against the head line, the whole head line when it does not match.  Empty: the
+    // default `^([^\s]+)\s?`, which needs no regular-expression engine (head line up to the first white space).
+    std::string id_regexp;
+    std::shared_ptr<std::regex> id_re;
     bool host_parse = false;      // --host-parse: records are scanned and printed by the host
                                   // (needed for multi-line FASTQ); default: file text is parsed
                                   // and, for seq, formatted on the GPU
@@ -129,5 +136,8 @@ int cmd_stats(const GlobalOpts& g, const StatsOpts& o, const std::vector<std::st
 
 // "[ERRO] msg" on stderr and the reference's exit status (os.Exit(-1) -> 255)
 int fatal(const std::string& msg);
+
+// Where the ID lies inside a head line: [*off, *off + *len) of name[0, n).
+void id_span(const GlobalOpts& g, const uint8_t* name, uint32_t n, uint32_t* off, uint32_t* len);
 
 }  // namespace host

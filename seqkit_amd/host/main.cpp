@@ -177,8 +177,16 @@ int main(int argc, char** argv)
     g.batch_records = strtoull(p.value("batch-records", "4194304").c_str(), nullptr, 10);
     g.host_parse = p.has("host-parse");
     if (p.has("batch-bytes")) g.text_block_bytes = g.batch_bytes;
-    if (p.has("id-regexp") || p.has("id-ncbi"))
-        return fatal("--id-regexp / --id-ncbi are not supported by this driver (default ID rule only)");
+    if (p.has("id-ncbi")) g.id_regexp = "\\|([^\\|]+)\\| ";                  // helper.go:129-131
+    else if (p.has("id-regexp")) g.id_regexp = p.value("id-regexp", "");
+    if (g.id_regexp == "^([^\\s]+)\\s?") g.id_regexp.clear();                // fastx.DefaultIDRegexp
+    if (!g.id_regexp.empty()) {
+        if (g.id_regexp.find('(') == std::string::npos || g.id_regexp.find(')') == std::string::npos)
+            return fatal("regular expression must contain \"(\" and \")\" to capture matched ID. default: `^([^\\s]+)\\s?`");
+        if (g.host_parse) return fatal("--id-regexp / --id-ncbi are not available with --host-parse");
+        try { g.id_re = std::make_shared<std::regex>(g.id_regexp, std::regex::ECMAScript | std::regex::optimize); }
+        catch (const std::regex_error& e) { return fatal(std::string("error parsing regexp: ") + e.what()); }
+    }
     std::vector<std::string> files = p.args;
     if (files.empty()) files.push_back("-");                                // helper.go:55-56
 

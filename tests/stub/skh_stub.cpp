@@ -477,6 +477,20 @@ int skh_text_names(skh_ctx* cx, skh_text* t, uint64_t first, uint64_t count, uin
     }
     return SKH_OK;
 }
+int skh_text_set_names(skh_ctx* cx, skh_text* t, uint64_t first, uint64_t count, const uint64_t* pos, const uint32_t* len)
+{
+    if (!t || ((!pos || !len) && count)) return fail(SKH_EINVAL, "NULL argument");
+    if (t->ctx != cx) return fail(SKH_EINVAL, "the text block belongs to another context");
+    if (first + count > t->nrec) return fail(SKH_EINVAL, "record range beyond the block");
+    if (t->names_external) return fail(SKH_EINVAL, "the block's names no longer lie in its text buffer");
+    for (uint64_t i = 0; i < count; i++) {
+        if (pos[i] < t->text_off || pos[i] + len[i] > t->text_off + t->text.size())
+            return fail(SKH_EINVAL, "a name span lies outside the parsed text");
+        t->npos[first + i] = pos[i] - t->text_off;
+        t->nlen[first + i] = len[i];
+    }
+    return SKH_OK;
+}
 int skh_text_name(skh_ctx* c, skh_text* t, uint64_t record, uint64_t* pos, uint32_t* len)
 {
     if (!pos || !len) return fail(SKH_EINVAL, "NULL argument");
