@@ -89,7 +89,7 @@ int main(int argc, char **argv)
         if (is_flag(a, NULL, "--quiet")) { so.quiet = 1; continue; }
         if (is_flag(a, NULL, "--id-ncbi")) { ora_set_id_regexp("\\|([^\\|]+)\\| "); continue; }          /* helper.go:129-131 */
         if (is_flag(a, NULL, "--id-regexp")) {
-            const char *v = value_of(&i, argc, argv);
+            const char *v = NEXT();
             if (!v || ora_set_id_regexp(v) != 0) {
                 fprintf(stderr, "[ERRO] regular expression must contain \"(\" and \")\" to capture matched ID. default: `^([^\\s]+)\\s?`\n");
                 return 255;

@@ -29,6 +29,9 @@ VECTORS = {
         ["seq", "hairpin.fa.gz", "-n"], "head3", "full names"),
     "G1e_seq_ids_head": ("doc/docs/usage.md", 339, 341, 12,
         ["seq", "hairpin.fa.gz", "-n", "-i"], "head3", "IDs"),
+    "G1f_seq_custom_ids_head": ("doc/docs/usage.md", 346, 348, 12,
+        ["seq", "hairpin.fa.gz", "-n", "-i", "--id-regexp", "^[^\\s]+\\s([^\\s]+)\\s"], "head3",
+        "IDs cut out by a custom --id-regexp (capture group 1)"),
     "G2_fx2tab_len_gc_head": ("doc/docs/usage.md", 795, 798, 8,
         ["fx2tab", "hairpin.fa.gz", "-l", "-g", "-n", "-i", "-H"], "fields4",
         "piped through `csvtk pretty` in the doc: compare whitespace-split fields of the first 4 lines"),

@@ -153,3 +153,23 @@ def test_stats_type_follows_seq_type_flag(san, oracle_cli):
         got = clean(run_cli(san["asan"], ["stats", "-T", "-t", "protein"] + mode + ["contigs.fa"]))
         want = run_cli(oracle_cli, ["stats", "-T", "-t", "protein", "contigs.fa"])
         assert got[1] == want[1] and b"\tProtein\t" in got[1]
+
+
+def test_custom_id_regexp(san, oracle_cli, tmp_path):
+    # root.go:68-69, helper.go:125-135: the ID is capture group 1 of --id-regexp, the whole head line
+    # where it does not match; --id-ncbi is a fixed expression.  doc/docs/usage.md:345-348 pins one case
+    # (golden vector G1f); the rest is compared with the oracle's restatement.
+    ncbi = tmp_path / "ncbi.fa"
+    ncbi.write_text(">gi|110645304|ref|NC_002516.2| Pseudomona\nACGTACGT\n>plain one\nAC\n>gi|9|ref|X_1.1| other\nGGCC\n")
+    cases = [(["seq", "-n", "-i", "--id-regexp", r"^[^\s]+\s([^\s]+)\s"], "hairpin.fa.gz"),
+             (["fx2tab", "-i", "-l", "--id-regexp", r"^[^\s]+\s([^\s]+)\s"], "mature.fa.gz"),
+             (["seq", "-i", "--id-regexp", r"^(\w+)-"], "hairpin.fa.gz"),
+             (["seq", "-n", "-i", "--id-ncbi"], str(ncbi)), (["fx2tab", "-n", "-i", "--id-regexp", r"^gi\|([^\|]+)\|"], str(ncbi)),
+             (["seq", "-n", "-i", "--id-regexp", r"^([^\s]+)\s?"], "reads_1.fq.gz")]
+    for argv, f in cases:
+        want = run_cli(oracle_cli, argv + [f])
+        for extra in ([], ["--batch-bytes", "8192"]):
+            got = clean(run_cli(san["asan"], argv + extra + [f]))
+            assert got[0] == want[0] == 0 and got[1] == want[1], (argv, extra)
+    rc, _, err = run_cli(san["asan"], ["seq", "-n", "-i", "--id-regexp", "abc", "contigs.fa"])
+    assert rc == 255 and b"regular expression must contain" in err

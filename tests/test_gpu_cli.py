@@ -504,3 +504,19 @@ def test_convert_files_through_the_block_pipeline(cli, oracle_cli, tmp_path):
     text = short.read_text()
     for n in ("39", "40", "41"):
         assert run_cli(cli, to13 + ["-n", n], stdin=text) == run_cli(oracle_cli, to13 + ["-n", n], stdin=text)
+
+
+def test_custom_id_regexp(cli, oracle_cli, tmp_path):
+    # --id-regexp / --id-ncbi (root.go:68-69): IDs cut out on the host, printed by the GPU formatter
+    ncbi = tmp_path / "ncbi.fa"
+    ncbi.write_text(">gi|110645304|ref|NC_002516.2| Pseudomona\nACGTACGT\n>plain one\nAC\n>gi|9|ref|X_1.1| other\nGGCC\n")
+    cases = [(["seq", "-n", "-i", "--id-regexp", r"^[^\s]+\s([^\s]+)\s"], "hairpin.fa.gz"),
+             (["fx2tab", "-i", "-l", "-g", "--id-regexp", r"^[^\s]+\s([^\s]+)\s"], "mature.fa.gz"),
+             (["seq", "-i", "-r", "-p", "--id-regexp", r"^(\w+)-"], "hairpin.fa.gz"),
+             (["seq", "-n", "-i", "--id-ncbi"], str(ncbi)), (["fx2tab", "-n", "-i", "--id-regexp", r"^gi\|([^\|]+)\|"], str(ncbi))]
+    for argv, f in cases:
+        want = run_cli(oracle_cli, argv + [f])
+        for extra in ([], ["--batch-bytes", "8192"], ["--devices", "0,0", "--batch-bytes", "8192"]):
+            got = run_cli(cli, argv + extra + [f])
+            assert got[0] == want[0] == 0 and got[1] == want[1], (argv, extra)
+
