@@ -79,6 +79,7 @@ def parse():
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the file-to-file run of the driver")
     ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configurations")
+    ap.add_argument("--no-collective", action="store_true", help="skip the RCCL all-reduce of the stats totals (profiler passes)")
     return ap.parse_args()
 
 
@@ -455,31 +456,34 @@ def main():
     # library over RCCL (one rank per process; the id travels over torch.distributed's own channel)
     stats_d = torch.zeros(5, dtype=torch.int64, device=dev)
     stats_ms = b.time_ms(lambda: b.stats(seq, offs, nrec, total, stats_d), reps=10)
-    idbuf = torch.zeros(128, dtype=torch.uint8, device=dev)
-    if rank == 0:
-        raw = (C.c_uint8 * 128)()
-        lib.check(lib.skh_comm_unique_id(raw))
-        idbuf.copy_(torch.tensor(list(raw), dtype=torch.uint8))
-    if world > 1:
-        dist.broadcast(idbuf, src=0)
-    raw = (C.c_uint8 * 128)(*[int(x) for x in idbuf.cpu()])
-    comm = C.c_void_p()
-    t_init = time.perf_counter()
-    lib.check(lib.skh_comm_init_rank(ctx, raw, world, rank, C.byref(comm)))
-    comm_init_s = time.perf_counter() - t_init
-    dparts, streams = (C.c_void_p * 1)(stats_d.data_ptr()), (C.c_void_p * 1)(stream.cuda_stream)
-    allreduce_us = []
-    for it in range(4):                                   # the first call sets up RCCL's channels
-        b.stats(seq, offs, nrec, total, stats_d)
-        barrier()
-        ta = time.perf_counter()
-        lib.check(lib.skh_stats_allreduce_dev(comm, dparts, streams))
-        torch.cuda.synchronize()
-        allreduce_us.append((time.perf_counter() - ta) * 1e6)
-    stats = [int(x) for x in stats_d.cpu()]
-    ok_stats = stats[:2] == [nrec * world, total * world] and stats[3:] == [L, L]
-    assert ok_stats, stats
-    lib.skh_comm_destroy(comm)
+    allreduce_us, comm_init_s = [], None
+    if args.no_collective:
+        stats = [int(x) for x in stats_d.cpu()]
+    else:
+        idbuf = torch.zeros(128, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            raw = (C.c_uint8 * 128)()
+            lib.check(lib.skh_comm_unique_id(raw))
+            idbuf.copy_(torch.tensor(list(raw), dtype=torch.uint8))
+        if world > 1:
+            dist.broadcast(idbuf, src=0)
+        raw = (C.c_uint8 * 128)(*[int(x) for x in idbuf.cpu()])
+        comm = C.c_void_p()
+        t_init = time.perf_counter()
+        lib.check(lib.skh_comm_init_rank(ctx, raw, world, rank, C.byref(comm)))
+        comm_init_s = time.perf_counter() - t_init
+        dparts, streams = (C.c_void_p * 1)(stats_d.data_ptr()), (C.c_void_p * 1)(stream.cuda_stream)
+        for it in range(4):                                   # the first call sets up RCCL's channels
+            b.stats(seq, offs, nrec, total, stats_d)
+            barrier()
+            ta = time.perf_counter()
+            lib.check(lib.skh_stats_allreduce_dev(comm, dparts, streams))
+            torch.cuda.synchronize()
+            allreduce_us.append((time.perf_counter() - ta) * 1e6)
+        stats = [int(x) for x in stats_d.cpu()]
+        ok_stats = stats[:2] == [nrec * world, total * world] and stats[3:] == [L, L]
+        assert ok_stats, stats
+        lib.skh_comm_destroy(comm)
 
     ok = True
     if not args.no_verify:
@@ -539,7 +543,8 @@ def main():
             },
             "stats": {"totals": stats, "collective": "skh_stats_allreduce_dev: RCCL all-reduce of 5 x int64 (sum x3, min, max) "
                                                      "inside libseqkit_hip.so, %d rank(s)" % world,
-                      "allreduce_us": [round(x, 1) for x in allreduce_us], "comm_init_s": round(comm_init_s, 3)},
+                      "allreduce_us": [round(x, 1) for x in allreduce_us],
+                      "comm_init_s": None if comm_init_s is None else round(comm_init_s, 3)},
             "verified": ok,
         }
         if configs is not None:
