@@ -117,10 +117,10 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_prepare(const uint64_t* __restric
 // log2 of the lanes per record a short kernel works with: the host's choice, lowered to what the
 // sampled short records ask for (never raised: the grid was sized for the host's choice).
 template <bool COUNT>
-__device__ __forceinline__ int hinted_logG(int logG_host, const BatchHint* hint, int use_hint)
+__device__ __forceinline__ int hinted_logG(int logG_host, uint32_t mean_short, int use_hint)
 {
     if (!use_hint) return logG_host;
-    const uint32_t mean = __builtin_amdgcn_readfirstlane(hint->mean_short);
+    const uint32_t mean = __builtin_amdgcn_readfirstlane(mean_short);
     if (mean == ~0u) return logG_host;
     const int lg = COUNT ? lanes_log2_count(mean) : lanes_log2_reverse(mean);
     return lg < logG_host ? lg : logG_host;
@@ -539,9 +539,10 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_reverse_staged(const uint8_t* __r
                                                               BatchHint* __restrict__ hint, int use_hint)
 {
     __shared__ StageLds S;
+    const uint32_t mean_short = hint->mean_short;        // asked for before the table set-up, needed after it
     rev_lds_init<COMP>(S.tab, lut);
     uint32_t* n_long = &hint->n_long;
-    const int logG = hinted_logG<false>(logG_host, hint, use_hint);
+    const int logG = hinted_logG<false>(logG_host, mean_short, use_hint);
     const uint32_t G = 1u << logG, j = threadIdx.x & (G - 1);
     const uint32_t lane = threadIdx.x & 63, GW = 64u >> logG, g = lane >> logG;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1079,9 +1080,10 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_count_short(
     BatchHint* __restrict__ hint, int use_hint)
 {
     __shared__ CountLds<NW> L;
+    const uint32_t mean_short = hint->mean_short;        // asked for before the table set-up, needed after it
     count_lds_init<NW>(L, cls);
     uint32_t* n_long = &hint->n_long;
-    const int logG = hinted_logG<true>(logG_host, hint, use_hint);
+    const int logG = hinted_logG<true>(logG_host, mean_short, use_hint);
     constexpr int U = 3;
     const bool has_neutral = neutral < 256u;
     const uint32_t neutral4 = (neutral & 0xffu) * 0x01010101u;
@@ -1113,23 +1115,62 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_count_short(
 #pragma unroll
             for (int i = 0; i < NW; i++) acc8[i] = 0;
             const uint64_t o0 = s & ~15ull;
-            const uint32_t K = (uint32_t)((e - o0 + 15) >> 4);
-            uint32_t pending = 0;
-            for (uint32_t kb = 0; kb < K; kb += U * G) {
-                uint4 V[U];
+            const uint32_t sp = (uint32_t)(s - o0);         // bytes of chunk 0 in front of the record
+            const uint32_t span = (uint32_t)(e - o0);       // from chunk 0 to the record's end: <= LONG_T + 15
+            const uint32_t K = (span + 15) >> 4;
+            if (has_neutral) {
+                // The vector ALUs, not the memory system, are what this kernel runs out of first, so the
+                // loop body is kept to the lookups: every chunk is masked the same way, without a
+                // branch -- bytes [lo, hi) of it are the record's, the others are replaced by a byte of
+                // no class (for a lane past the record's last chunk that is all of them) -- and the
+                // 8-bit fields are widened on a count of rounds, not of chunks.
+                uint32_t rounds = 0;
+                for (uint32_t kb = 0; kb < K; kb += U * G) {
+                    uint4 V[U];
 #pragma unroll
-                for (int u = 0; u < U; u++) {            // all loads of the step before the first use:
-                    const uint32_t k = kb + j + u * G;   // unconditional (a lane without a chunk re-reads
-                    V[u] = ld16(seq + o0 + 16ull * (k < K ? k : 0));   // chunk 0) so they issue back to back
+                    for (int u = 0; u < U; u++) {            // all loads of the round before the first use:
+                        const uint32_t k = kb + j + u * G;   // unconditional (a lane without a chunk re-reads
+                        V[u] = ld16(seq + o0 + 16ull * (k < K ? k : 0));   // chunk 0) so they issue back to back
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        const uint32_t k = kb + j + u * G;
+                        if (!__any(k < K)) continue;         // wave-uniform: no lane has a chunk in this slot
+                        const int rem = (int)span - 16 * (int)k;
+                        const uint32_t hi = rem >= 16 ? 16u : (rem > 0 ? (uint32_t)rem : 0u);
+                        uint4 m = L.low[hi];
+                        if (u == 0 && __any(k == 0 && sp != 0)) {    // wave-uniform: a record starts inside its chunk 0
+                            const uint4 ml = L.low[k == 0 ? sp : 0u];   // (sp < span: the record is not empty)
+                            m.x ^= ml.x; m.y ^= ml.y; m.z ^= ml.z; m.w ^= ml.w;
+                        }
+                        uint4 v = V[u];
+                        v.x = (v.x & m.x) | (neutral4 & ~m.x);
+                        v.y = (v.y & m.y) | (neutral4 & ~m.y);
+                        v.z = (v.z & m.z) | (neutral4 & ~m.z);
+                        v.w = (v.w & m.w) | (neutral4 & ~m.w);
+                        count4<NW>(v.x, L.lut, acc8);
+                        count4<NW>(v.y, L.lut, acc8);
+                        count4<NW>(v.z, L.lut, acc8);
+                        count4<NW>(v.w, L.lut, acc8);
+                    }
+                    if (++rounds == 15 / U) {                // 15 chunks * 16 bytes = 240 < 256 per field
+                        widen<NW>(acc8, acc16);
+                        rounds = 0;
+                    }
                 }
-#pragma unroll
-                for (int u = 0; u < U; u++) {
-                    const uint32_t k = kb + j + u * G;
-                    if (k < K) {
-                        count_loaded<NW>(V[u], s, e, o0 + 16ull * k, L, neutral4, has_neutral, acc8);
-                        if (++pending == 15) {           // 15 chunks * 16 bytes = 240 < 256 per field
-                            widen<NW>(acc8, acc16);
-                            pending = 0;
+            } else {
+                // every byte value has a class: bytes outside the record are skipped one by one
+                uint32_t pending = 0;
+                for (uint32_t kb = 0; kb < K; kb += U * G) {
+#pragma unroll 1
+                    for (int u = 0; u < U; u++) {
+                        const uint32_t k = kb + j + u * G;
+                        if (k < K) {
+                            count_chunk<NW>(seq, s, e, o0 + 16ull * k, L, neutral4, false, acc8);
+                            if (++pending == 15) {
+                                widen<NW>(acc8, acc16);
+                                pending = 0;
+                            }
                         }
                     }
                 }
