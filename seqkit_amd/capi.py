@@ -74,6 +74,7 @@ SYMBOLS = {
     "skh_class_table": (C.c_int, [C.POINTER(C.c_char_p), C.c_uint32, u8p]),
     "skh_revcomp_dev": (C.c_int, [vp, vp, vp, vp, C.c_uint64, C.c_uint64, u8p, C.c_int, vp]),
     "skh_revcomp_fastq_dev": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_uint64, C.c_uint64, u8p, C.c_int, vp]),
+    "skh_revcomp_inplace_dev": (C.c_int, [vp, vp, vp, vp, C.c_uint64, C.c_uint64, u8p, C.c_int, vp]),
     "skh_count_dev": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_uint64, u8p, C.c_uint32, vp, vp]),
     "skh_stats_dev": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_uint64, u8p, vp, vp]),
     "skh_stats_static_dev": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_uint64, u8p, vp, vp]),

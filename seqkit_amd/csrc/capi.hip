@@ -368,6 +368,35 @@ int skh_revcomp_fastq_dev(skh_ctx* ctx, const uint8_t* d_seq_in, uint8_t* d_seq_
                         do_reverse, st);
 }
 
+int skh_revcomp_inplace_dev(skh_ctx* ctx, uint8_t* d_seq, uint8_t* d_qual, const uint64_t* d_offsets,
+                            uint64_t nrec, uint64_t total_bytes, const uint8_t* lut, int do_reverse, void* stream)
+{
+    if (!ctx) return fail(SKH_EINVAL, "ctx is NULL");
+    int rc = check_plane_args(d_seq, d_offsets, nrec, total_bytes);
+    if (rc) return rc;
+    if (reinterpret_cast<uintptr_t>(d_qual) & 15) return fail(SKH_EINVAL, "quality plane is not 16-byte aligned");
+    if (d_qual && d_qual == d_seq) return fail(SKH_EINVAL, "sequence and quality planes are the same memory");
+    if (total_bytes == 0) return SKH_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    skh::Table256 t;
+    if (lut) memcpy(t.v, lut, 256);
+    const skh::LaunchCfg cfg = cfg_for(ctx, nrec, total_bytes);
+    if (!do_reverse) {
+        // every 16-byte chunk is read and then written by the same lane; qualities stay as they are
+        if (lut) HIP_TRY(skh::launch_map_plane(cfg, d_seq, d_seq, total_bytes, t, st));
+        return SKH_OK;
+    }
+    uint32_t slot;
+    if ((rc = slot_for(ctx, st, &slot))) return rc;
+    // the launches of one stream run in order, so the planes can share the launch scratch
+    HIP_TRY(skh::launch_reverse_inplace(cfg, d_seq, d_offsets, nrec, total_bytes, lut ? &t : nullptr,
+                                        ctx->d_hints + slot, st));
+    if (d_qual)
+        HIP_TRY(skh::launch_reverse_inplace(cfg, d_qual, d_offsets, nrec, total_bytes, nullptr, ctx->d_hints + slot, st));
+    return SKH_OK;
+}
+
 int skh_count_dev(skh_ctx* ctx, const uint8_t* d_seq, const uint64_t* d_offsets, uint64_t nrec,
                   uint64_t total_bytes, const uint8_t class_of[256], uint32_t nclass, uint64_t* d_counts,
                   void* stream)

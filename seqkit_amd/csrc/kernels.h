@@ -62,6 +62,9 @@ __host__ __device__ inline int lanes_log2_count(uint64_t mean)
 hipError_t launch_reverse(const LaunchCfg& cfg, const uint8_t* in, uint8_t* out, const uint8_t* qin,
                           uint8_t* qout, const uint64_t* offs, uint64_t nrec, uint64_t total,
                           const Table256* lut, BatchHint* hint, hipStream_t st);
+// The same with one plane for input and output (reverse, or reverse + map through lut).
+hipError_t launch_reverse_inplace(const LaunchCfg& cfg, uint8_t* plane, const uint64_t* offs, uint64_t nrec,
+                                  uint64_t total, const Table256* lut, BatchHint* hint, hipStream_t st);
 hipError_t launch_map_plane(const LaunchCfg& cfg, const uint8_t* in, uint8_t* out, uint64_t total,
                             const Table256& lut, hipStream_t st);
 // neutral: a byte value of no class, or 256 if every byte value has a class.

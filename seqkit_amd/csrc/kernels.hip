@@ -776,6 +776,182 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_reverse_tiles(RevPlanes P, uint64
     });
 }
 
+// ---- in place --------------------------------------------------------------------------
+//
+// out == in: a byte may only be overwritten by a lane that has already read everything the
+// new bytes are made of.  A record [s, e) is taken as pairs of 16-byte windows at the same
+// distance from its two ends, [s + 16 i, +16) and [e - 16 i - 16, +16): one lane loads both and
+// stores each, reversed, in the other's place; it shares no byte with any other lane, whatever
+// the alignment of s and e (gfx950 global loads and stores take any byte address).  What is
+// left between the innermost pair (fewer than 32 bytes) goes to the lane of that pair, as
+// windows that overlap bytes the lane has loaded and not yet stored: two windows when at least
+// 16 bytes are left, otherwise one window that reaches back into the innermost pair.
+// Overlapping stores carry the same, final bytes, so their order does not matter.  Records
+// shorter than 16 bytes are swapped byte by byte.
+
+__device__ __forceinline__ void stu16(uint8_t* p, uint4 v)      // any byte address
+{
+    __builtin_memcpy(p, &v, 16);
+}
+
+template <bool COMP>
+__device__ __forceinline__ uint4 reversed_mapped(uint4 v, const uint8_t* s_lut)
+{
+    v = reverse16(v);
+    return COMP ? map16(v, s_lut) : v;
+}
+
+// The middle [m0, m0 + M) of a record, 0 < M < 32, between windows the caller has loaded but not
+// stored yet (or, with M >= 16, on its own).  load() before the caller's stores, store() after.
+template <bool COMP>
+struct MiddleInPlace {
+    uint4 x, y;
+    __device__ __forceinline__ void load(const uint8_t* p, uint64_t m0, uint32_t M)
+    {
+        x = ldu16(p + m0);                            // M < 16: reaches into the back window of the innermost pair
+        if (M >= 16) y = ldu16(p + m0 + M - 16);
+    }
+    __device__ __forceinline__ void store(uint8_t* p, uint64_t m0, uint32_t M, const uint8_t* s_lut) const
+    {
+        // [m0 + M - 16, m0 + M) is the mirror image of [m0, m0 + 16)
+        stu16(p + m0 + M - 16, reversed_mapped<COMP>(x, s_lut));
+        if (M >= 16) stu16(p + m0, reversed_mapped<COMP>(y, s_lut));
+    }
+};
+
+// [a, b) reversed byte by byte (a handful of bytes)
+template <bool COMP>
+__device__ __forceinline__ void reverse_bytes_inplace(uint8_t* p, uint64_t a, uint64_t b, const uint8_t* s_lut)
+{
+    while (b - a >= 2) {
+        b--;
+        const uint8_t x = p[a], y = p[b];
+        p[a] = COMP ? s_lut[y] : y;
+        p[b] = COMP ? s_lut[x] : x;
+        a++;
+    }
+    if (COMP && b - a == 1) p[a] = s_lut[p[a]];
+}
+
+// Records of at most LONG_T bytes: a group of 2^logG lanes per record, lane j takes the window
+// pairs j, j + G, ...
+template <bool COMP>
+__global__ __launch_bounds__(SKH_BLOCK) void k_reverse_inplace_short(uint8_t* __restrict__ p,
+                                                                     const uint64_t* __restrict__ offs, uint64_t total,
+                                                                     uint64_t nrec, Table256 lut, int logG_host,
+                                                                     BatchHint* __restrict__ hint, int use_hint)
+{
+    __shared__ RevLds L;
+    const uint32_t mean_short = hint->mean_short;
+    rev_lds_init<COMP>(L, lut);
+    uint32_t* n_long = &hint->n_long;
+    const int logG = hinted_logG<false>(logG_host, mean_short, use_hint);
+    const uint32_t G = 1u << logG, j = threadIdx.x & (G - 1);
+    const uint32_t lane = threadIdx.x & 63, GW = 64u >> logG, g = lane >> logG;
+    const uint64_t stride = (uint64_t)gridDim.x * (SKH_BLOCK / 64) * GW;
+    uint64_t rec0 = ((uint64_t)xcd_remap(blockIdx.x, gridDim.x) * (SKH_BLOCK / 64) + (threadIdx.x >> 6)) * GW;
+    if (rec0 >= nrec) return;
+    WaveOffsets wo;
+    wo.load(offs, nrec, total, rec0, GW, lane);
+    while (true) {
+        const uint64_t next0 = rec0 + stride;
+        WaveOffsets nwo;
+        if (next0 < nrec) nwo.load(offs, nrec, total, next0, GW, lane);
+        const uint64_t s = wo.get(g + 1, GW), e = wo.get(g + 2, GW);
+        const uint64_t len = e - s;
+        if (len > SKH_LONG_T) {
+            if (j == 0) atomicAdd(n_long, 1u);
+        } else if (len >= 16) {
+            const uint32_t n = (uint32_t)len >> 5, M = (uint32_t)len & 31u;       // pairs, bytes between them
+            const uint64_t m0 = s + 16ull * n;
+            if (n == 0) {
+                if (j == 0) {
+                    MiddleInPlace<COMP> mid;
+                    mid.load(p, m0, M);
+                    mid.store(p, m0, M, L.lut);
+                }
+            } else {
+                for (uint32_t i = j; i < n; i += G) {
+                    const uint64_t f = s + 16ull * i, b = e - 16ull * i - 16;
+                    const bool inner = i == n - 1 && M != 0;
+                    const uint4 F = ldu16(p + f), B = ldu16(p + b);
+                    MiddleInPlace<COMP> mid;
+                    if (inner) mid.load(p, m0, M);
+                    stu16(p + f, reversed_mapped<COMP>(B, L.lut));
+                    stu16(p + b, reversed_mapped<COMP>(F, L.lut));
+                    if (inner) mid.store(p, m0, M, L.lut);
+                }
+            }
+        } else if (len != 0 && j == 0) {
+            reverse_bytes_inplace<COMP>(p, s, e, L.lut);
+        }
+        if (next0 >= nrec) break;
+        rec0 = next0;
+        wo = nwo;
+    }
+}
+
+// Longer records: a workgroup serves the window pairs whose FRONT window starts in its run of the
+// plane (workgroups whose runs lie in the back halves of records find nothing to do).  The front
+// windows are moved to 16-byte alignment: the h = -s mod 16 bytes at either end of the record are
+// swapped byte by byte by the workgroup that holds s.
+template <bool COMP>
+__global__ __launch_bounds__(SKH_BLOCK) void k_reverse_inplace_long(uint8_t* __restrict__ p,
+                                                                    const uint64_t* __restrict__ offs, uint64_t total,
+                                                                    uint64_t nrec, Table256 lut,
+                                                                    const BatchHint* __restrict__ hint)
+{
+    if (hint->n_long == 0) return;
+    __shared__ RevLds L;
+    __shared__ WalkLds W;
+    rev_lds_init<COMP>(L, lut);
+    constexpr int U = 4;
+    const uint64_t t0 = (uint64_t)blockIdx.x * LONG_RUN;
+    if (t0 >= total) return;
+    const uint64_t t1 = t0 + LONG_RUN < total ? t0 + LONG_RUN : total;
+    for_each_long(offs, nrec, t0, t1, W, [&](uint64_t, uint64_t s, uint64_t e) {
+        const uint32_t h = (uint32_t)(-(int64_t)s) & 15u;
+        const uint64_t fs = s + h, be = e - h;                      // windows cover [fs, be); fs is aligned
+        const uint64_t len = be - fs;                               // > LONG_T - 30
+        const uint64_t n = len >> 5;
+        const uint32_t M = (uint32_t)len & 31u;
+        const uint64_t m0 = fs + 16 * n;
+        // pairs whose front window starts in [t0, t1)
+        const uint64_t i0 = fs >= t0 ? 0 : (t0 - fs) >> 4;
+        uint64_t i1 = fs >= t1 ? 0 : (t1 - fs + 15) >> 4;
+        if (i1 > n) i1 = n;
+        for (uint64_t ib = i0; ib < i1; ib += (uint64_t)U * SKH_BLOCK) {
+            uint4 F[U], B[U];
+            MiddleInPlace<COMP> mid;
+            bool inner = false;
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint64_t i = ib + threadIdx.x + (uint64_t)u * SKH_BLOCK;
+                if (i < i1) {
+                    F[u] = ld16(p + fs + 16 * i);
+                    B[u] = ldu16(p + be - 16 * i - 16);
+                    if (i == n - 1 && M != 0) inner = true;
+                }
+            }
+            if (inner) mid.load(p, m0, M);
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint64_t i = ib + threadIdx.x + (uint64_t)u * SKH_BLOCK;
+                if (i < i1) {
+                    *reinterpret_cast<uint4*>(p + fs + 16 * i) = reversed_mapped<COMP>(B[u], L.lut);
+                    stu16(p + be - 16 * i - 16, reversed_mapped<COMP>(F[u], L.lut));
+                }
+            }
+            if (inner) mid.store(p, m0, M, L.lut);
+        }
+        if (h != 0 && s >= t0 && s < t1 && threadIdx.x < h) {       // the unaligned ends, one byte pair per thread
+            const uint8_t x = p[s + threadIdx.x], y = p[e - 1 - threadIdx.x];
+            p[s + threadIdx.x] = COMP ? L.lut[y] : y;
+            p[e - 1 - threadIdx.x] = COMP ? L.lut[x] : x;
+        }
+    });
+}
+
 // ---- span form: lanes own consecutive output chunks of the plane ------------------------
 //
 // A workgroup walks a contiguous range of the plane in spans of U*256 aligned
@@ -934,19 +1110,27 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_reverse_span(RevPlanes P, uint64_
 }
 
 // No reversal: out[i] = lut[in[i]] over the whole plane (record boundaries do not matter).
-__global__ __launch_bounds__(SKH_BLOCK) void k_map_plane(const uint8_t* __restrict__ in,
-                                                         uint8_t* __restrict__ out, uint64_t total,
-                                                         Table256 lut)
+// The grid covers the plane once, MAP_U chunks per lane, all loads of a lane ahead of its first
+// table lookup; in == out is allowed (a chunk is read and written by the same lane).
+constexpr int MAP_U = 4;
+
+__global__ __launch_bounds__(SKH_BLOCK) void k_map_plane(const uint8_t* in, uint8_t* out, uint64_t total, Table256 lut)
 {
     __shared__ uint8_t s_lut[256];
     s_lut[threadIdx.x] = lut.v[threadIdx.x];
     __syncthreads();
     const uint64_t nchunk = (total + 15) >> 4;
-    const uint64_t stride = (uint64_t)gridDim.x * SKH_BLOCK;
-    for (uint64_t c = (uint64_t)blockIdx.x * SKH_BLOCK + threadIdx.x; c < nchunk; c += stride) {
-        const uint64_t o = c << 4;
-        const uint4 v = map16(ld16(in + o), s_lut);
-        store_clipped(out, 0, total, o, v);
+    const uint64_t c0 = (uint64_t)blockIdx.x * (MAP_U * SKH_BLOCK) + threadIdx.x;
+    uint4 v[MAP_U];
+#pragma unroll
+    for (int u = 0; u < MAP_U; u++) {
+        const uint64_t c = c0 + (uint64_t)u * SKH_BLOCK;
+        if (c < nchunk) v[u] = ld16(in + (c << 4));
+    }
+#pragma unroll
+    for (int u = 0; u < MAP_U; u++) {
+        const uint64_t c = c0 + (uint64_t)u * SKH_BLOCK;
+        if (c < nchunk) store_clipped(out, 0, total, c << 4, map16(v[u], s_lut));
     }
 }
 
@@ -1656,9 +1840,37 @@ hipError_t launch_reverse(const LaunchCfg& cfg, const uint8_t* in, uint8_t* out,
 hipError_t launch_map_plane(const LaunchCfg& cfg, const uint8_t* in, uint8_t* out, uint64_t total,
                             const Table256& lut, hipStream_t st)
 {
-    const uint32_t g = grid_for((total + 15) >> 4, SKH_BLOCK, resident_cap(k_map_plane, cfg));
-    hipLaunchKernelGGL(k_map_plane, dim3(g), dim3(SKH_BLOCK), 0, st, in, out, total, lut);
+    (void)cfg;
+    const uint64_t per_block = (uint64_t)MAP_U * SKH_BLOCK;
+    const uint64_t g = (((total + 15) >> 4) + per_block - 1) / per_block;
+    if (g > 0x7fffffffull) return hipErrorInvalidValue;
+    if (g) hipLaunchKernelGGL(k_map_plane, dim3((uint32_t)g), dim3(SKH_BLOCK), 0, st, in, out, total, lut);
     return hipGetLastError();
+}
+
+template <bool COMP>
+static hipError_t launch_reverse_inplace_t(const LaunchCfg& cfg, uint8_t* plane, const uint64_t* offs, uint64_t nrec,
+                                           uint64_t total, const Table256& lut, BatchHint* hint, hipStream_t st)
+{
+    const uint32_t g1 = grid_for(nrec, SKH_BLOCK >> cfg.logG, resident_cap(k_reverse_inplace_short<COMP>, cfg));
+    hipLaunchKernelGGL((k_reverse_inplace_short<COMP>), dim3(g1), dim3(SKH_BLOCK), 0, st, plane, offs, total, nrec, lut,
+                       cfg.logG, hint, cfg.use_hint);
+    const uint64_t g2 = long_runs(total);
+    if (g2 > 0x7fffffffull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((k_reverse_inplace_long<COMP>), dim3((uint32_t)g2), dim3(SKH_BLOCK), 0, st, plane, offs, total,
+                       nrec, lut, hint);
+    return hipGetLastError();
+}
+
+hipError_t launch_reverse_inplace(const LaunchCfg& cfg, uint8_t* plane, const uint64_t* offs, uint64_t nrec,
+                                  uint64_t total, const Table256* lut, BatchHint* hint, hipStream_t st)
+{
+    if (nrec == 0 || total == 0) return hipSuccess;
+    hipError_t e = launch_prepare(offs, nrec, hint, st);
+    if (e != hipSuccess) return e;
+    if (lut) return launch_reverse_inplace_t<true>(cfg, plane, offs, nrec, total, *lut, hint, st);
+    Table256 none{};
+    return launch_reverse_inplace_t<false>(cfg, plane, offs, nrec, total, none, hint, st);
 }
 
 hipError_t launch_count(const LaunchCfg& cfg, const uint8_t* seq, const uint64_t* offs, uint64_t nrec,

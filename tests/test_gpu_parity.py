@@ -122,6 +122,54 @@ def test_transform_matches_oracle(lib, ctx, ora, case, mode):
         assert (got_q[total:] == 0xEE).all()
 
 
+def run_revcomp_inplace(lib, ctx, seq, qual, offs, lut, do_reverse):
+    import torch
+    total = int(offs[-1])
+    d_seq, d_offs = to_dev(seq), to_dev(offs)
+    d_qual = to_dev(qual) if qual is not None else None
+    lutp = np.ascontiguousarray(lut, np.uint8).ctypes.data_as(C.POINTER(C.c_uint8)) if lut is not None else None
+    torch.cuda.synchronize()
+    lib.check(lib.skh_revcomp_inplace_dev(ctx, ptr(d_seq), ptr(d_qual) if qual is not None else None, ptr(d_offs),
+                                          len(offs) - 1, total, lutp, int(do_reverse), None))
+    lib.check(lib.skh_sync(ctx))
+    return d_seq.cpu().numpy(), d_qual.cpu().numpy() if qual is not None else None
+
+
+@pytest.fixture(scope="module")
+def ctx_default(lib):
+    c = lib.init(0)
+    yield c
+    lib.skh_destroy(c)
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+@pytest.mark.parametrize("mode", ["revcomp", "reverse", "complement", "fastq", "fastq_complement"])
+def test_inplace_matches_oracle(lib, ctx_default, ora, case, mode):
+    # one plane per kind, overwritten: (*Seq).ReverseInplace / ComplementInplace as the reference applies them
+    lengths = CASES[case]
+    fastq = mode.startswith("fastq")
+    seq, qual, offs = make_batch(lengths, seed=zlib.crc32(case.encode()) % 1000 + 1, letters=SOFT, with_qual=fastq)
+    total = int(offs[-1])
+    lut = ora.pair_table(1) if mode != "reverse" else None
+    do_reverse = mode not in ("complement", "fastq_complement")
+    want_s, want_q = ora.transform(seq, qual, offs, lut, do_reverse)
+    got_s, got_q = run_revcomp_inplace(lib, ctx_default, seq, qual, offs, lut, do_reverse)
+    assert np.array_equal(got_s[:total], want_s[:total])
+    assert np.array_equal(got_s[total:], seq[total:])            # the padding is not touched
+    if fastq:
+        assert np.array_equal(got_q[:total], want_q[:total])
+        assert np.array_equal(got_q[total:], qual[total:])
+
+
+def test_inplace_twice_is_identity(lib, ctx_default, ora):
+    lengths = np.concatenate([CASES["ragged0_300"], CASES["mixed_long"], CASES["tiny0_20"][:500]])
+    seq, qual, offs = make_batch(lengths, seed=5, letters=b"ACGTacgtN", with_qual=True)
+    lut = ora.pair_table(1)
+    once_s, once_q = run_revcomp_inplace(lib, ctx_default, seq, qual, offs, lut, True)
+    twice_s, twice_q = run_revcomp_inplace(lib, ctx_default, once_s, once_q, offs, lut, True)
+    assert np.array_equal(twice_s, seq) and np.array_equal(twice_q, qual)
+
+
 @pytest.mark.parametrize("logg", range(7))
 def test_every_group_width(lib, ora, logg, monkeypatch):
     # the lanes-per-record choice is a speed knob: every width must give the same bytes
@@ -136,6 +184,8 @@ def test_every_group_width(lib, ora, logg, monkeypatch):
         lut = ora.pair_table(3)
         want_s, want_q = ora.transform(seq, qual, offs, lut, True)
         got_s, got_q = run_revcomp(lib, c, seq, qual, offs, lut, True)
+        assert np.array_equal(got_s[:total], want_s[:total]) and np.array_equal(got_q[:total], want_q[:total])
+        got_s, got_q = run_revcomp_inplace(lib, c, seq, qual, offs, lut, True)
         assert np.array_equal(got_s[:total], want_s[:total]) and np.array_equal(got_q[:total], want_q[:total])
         cls = np.frombuffer(bytes(lib.class_table(["A", "C", "G", "T", "N-"])), np.uint8)
         assert np.array_equal(run_count(lib, c, seq, offs, cls, 5), ora.count(seq, offs, cls, 5))

@@ -17,4 +17,4 @@ for v in $values; do
   env $var=$v timeout -k 10 200 python3 tools/microbench_long.py || exit 1
 done
 } > $log 2>&1
-grep -E "^---|^==|revcomp|count4|stats|bench" $log
+grep -E "^---|^==|revcomp|inplace|count4|stats|bench" $log

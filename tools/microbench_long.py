@@ -39,6 +39,7 @@ def run(name, lengths, seed):
     seq = synth_plane(total, seed)
     offs = torch.from_numpy(offs_h).to(dev)
     out, back = torch.empty_like(seq), torch.empty_like(seq)
+    work = seq.clone()
     counts = torch.empty(nrec * 4, dtype=torch.int64, device=dev)
     stats = torch.zeros(5, dtype=torch.int64, device=dev)
     lut = lib.pair_table(1); cls = lib.class_table(["G", "C", "A", "T"])
@@ -48,6 +49,8 @@ def run(name, lengths, seed):
     st = torch.cuda.Stream(device=dev); sp = C.c_void_p(st.cuda_stream)
     ops = {
         "revcomp": (lambda: lib.skh_revcomp_dev(ctx, p(seq), p(out), p(offs), nrec, total, lut, 1, sp), 2 * total + 8 * nrec),
+        # in place: `work` holds the batch, reversed once more by every call (same work each time)
+        "inplace": (lambda: lib.skh_revcomp_inplace_dev(ctx, p(work), None, p(offs), nrec, total, lut, 1, sp), 2 * total + 8 * nrec),
         "count4": (lambda: lib.skh_count_dev(ctx, p(seq), p(offs), nrec, total, cls, 4, p(counts), sp), total + 40 * nrec),
         "stats": (lambda: lib.skh_stats_dev(ctx, p(seq), p(offs), nrec, total, gap, p(stats), sp), total + 8 * nrec),
     }
@@ -65,6 +68,13 @@ def run(name, lengths, seed):
     lib.skh_revcomp_dev(ctx, p(out), p(back), p(offs), nrec, total, lut, 1, sp)
     torch.cuda.synchronize()
     ok_rt = bool(torch.equal(back[:total], seq[:total]))
+    # the in-place form ran 2 + 5 times on `work`: once more gives the batch back, and then equals `out` after one more
+    lib.skh_revcomp_inplace_dev(ctx, p(work), None, p(offs), nrec, total, lut, 1, sp)
+    torch.cuda.synchronize()
+    ok_rt &= bool(torch.equal(work[:total], seq[:total]))
+    lib.skh_revcomp_inplace_dev(ctx, p(work), None, p(offs), nrec, total, lut, 1, sp)
+    torch.cuda.synchronize()
+    ok_rt &= bool(torch.equal(work[:total], out[:total]))
     c = counts.view(nrec, 4)
     acgt = sum(int(((seq[:total] == x) | (seq[:total] == x + 32)).sum()) for x in b"ACGT")
     ok_cnt = int(c.sum()) == acgt
@@ -76,7 +86,7 @@ def run(name, lengths, seed):
     lut_np = np.frombuffer(bytes(lut), np.uint8)
     ok_spot = bool(np.array_equal(r0, lut_np[i0[::-1]]))
     print("   roundtrip", ok_rt, "counts", ok_cnt, "stats", ok_st, "first-record", ok_spot)
-    del seq, out, back
+    del seq, out, back, work
     torch.cuda.empty_cache()
     return ok_rt and ok_cnt and ok_st and ok_spot
 
@@ -92,6 +102,8 @@ if "ont" in which:
 if "trim" in which:      # adapter-trimmed Illumina reads
     rng = np.random.default_rng(7)
     ok &= run("trimmed reads: uniform 30..151", rng.integers(30, 152, 8_000_000), 7)
+if "r150" in which:
+    ok &= run("fixed 150 bp", np.full(10_000_000, 150), 12)
 if "r100" in which:
     ok &= run("fixed 100 bp", np.full(10_000_000, 100), 8)
 if "r250" in which:
