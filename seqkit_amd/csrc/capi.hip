@@ -90,15 +90,17 @@ skh::LaunchCfg cfg_for(const skh_ctx* ctx, uint64_t nrec, uint64_t total)
     skh::LaunchCfg c;
     c.max_grid = ctx->max_grid;
     c.n_cu = ctx->n_cu;
-    // span kernel (lanes own consecutive output chunks) for read sets dominated by records of
-    // many KiB (nanopore-like: 54 % of HBM peak against 42 % for lane groups + windows); lane-group /
-    // staged kernels for short reads, and for records of megabytes the window kernel, whose windows
-    // then lie inside one record almost always (24 chromosomes: 63 % against 53 % for the span kernel).
-    // SKH_SPAN_U overrides.
+    // Reverse, records of at most LONG_T bytes.  Measured on resident batches of 2-10 Gbases (% of HBM peak,
+    // staged / direct / span kernel): reads of 100-250 bases 55-61 / 51-57 / -; 350 +- 70 bases 45 / 51 / -
+    // (a wavefront's stretch of 8 such records overflows the stage every other step); 700 +- 140: 50 / 56 / -;
+    // 1000 +- 200: 51 / 55 / 41; 4000 +- 800: 57 / 64 / 46; 16000 +- 3200: 59 / 60 / 54; nanopore-like
+    // log-normal lengths around 8 kb: 57 / 59 / 54.  So: the LDS-staged kernel for short reads, the direct
+    // lane-group kernel from a mean of 300 bases on; the span kernel (lanes own consecutive output chunks)
+    // only when SKH_SPAN_U asks for it.  SKH_STAGED = 0 / 1 overrides the first choice.
     const uint64_t mean_len = nrec ? total / nrec : 0;
-    c.span_u = ctx->span_u >= 0 ? ctx->span_u : ((mean_len >= 8192 && mean_len < (1ull << 20)) ? 4 : 0);
+    c.span_u = ctx->span_u >= 0 ? ctx->span_u : 0;
     c.fuse_fastq = ctx->fuse_fastq;
-    c.staged = ctx->staged;
+    c.staged = ctx->staged >= 0 ? ctx->staged : (mean_len < 300 ? 1 : 0);
     // staged reverse kernel, steps per wavefront (SKH_STAGED_STEPS overrides).  Measured on batches of
     // 5-10 M records: 150-base reads fastest with 2; 250-base reads 58 -> 63 % of HBM peak with 3;
     // reads of about 100 bases and ragged 30-151-base reads gain 4-5 points with 6, where fewer of
@@ -183,7 +185,7 @@ int skh_init(int device, skh_ctx** out)
     c->span_u = env_int("SKH_SPAN_U", -1);
     c->fuse_fastq = env_int("SKH_FUSE_FASTQ", 0);
     c->use_hint = env_int("SKH_HINT", 1);
-    c->staged = env_int("SKH_STAGED", 1);
+    c->staged = env_int("SKH_STAGED", -1);
     c->staged_steps = (uint32_t)env_int("SKH_STAGED_STEPS", 0);
     c->count_steps = (uint32_t)env_int("SKH_COUNT_STEPS", 0);
     c->stats_steps = (uint32_t)env_int("SKH_STATS_STEPS", 0);

@@ -19,10 +19,10 @@ struct skh_ctx {
     uint32_t max_grid = 0;
     uint32_t n_cu = 256;
     int force_logG = -1;
-    int span_u = -1;         // -1 = chosen per call from the mean record length
+    int span_u = -1;         // -1 = off (the span kernel runs on request only)
     int fuse_fastq = 0;
     int use_hint = 1;
-    int staged = 1;
+    int staged = -1;         // -1: by mean record length
     uint32_t staged_steps = 0;
     uint32_t count_steps = 0;
     uint32_t stats_steps = 0;

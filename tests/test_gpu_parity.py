@@ -24,9 +24,9 @@ def lib():
 
 # every reverse implementation must give the same bytes; the variables are read by skh_init
 KERNEL_SETS = {
-    "staged": {"SKH_SPAN_U": "0"},                                   # the default for short records
-    "span": {"SKH_SPAN_U": "4"},                                     # lanes own consecutive output chunks
-    "direct": {"SKH_SPAN_U": "0", "SKH_STAGED": "0"},                # lane groups without LDS staging
+    "staged": {"SKH_SPAN_U": "0", "SKH_STAGED": "1"},                # LDS-staged lane groups (default for short reads)
+    "span": {"SKH_SPAN_U": "4"},                                     # lanes own consecutive output chunks (on request only)
+    "direct": {"SKH_SPAN_U": "0", "SKH_STAGED": "0"},                # lane groups without LDS staging (default from 300 bases on)
     "fused": {"SKH_SPAN_U": "0", "SKH_STAGED": "0", "SKH_FUSE_FASTQ": "1"},   # bases and qualities in one launch
     "auto": {},                                                      # kernel chosen from the mean record length
 }

@@ -108,6 +108,10 @@ if "r100" in which:
     ok &= run("fixed 100 bp", np.full(10_000_000, 100), 8)
 if "r250" in which:
     ok &= run("fixed 250 bp", np.full(5_000_000, 250), 9)
+for tag, n, L in (("r350", 4_000_000, 350), ("r500", 4_000_000, 500), ("r700", 3_000_000, 700), ("r1k", 2_000_000, 1000), ("r4k", 500_000, 4000), ("r16k", 125_000, 16000)):
+    if tag in which:
+        rng = np.random.default_rng(L)
+        ok &= run("lengths uniform in %d +- 20 %%" % L, rng.integers(int(L * 0.8), int(L * 1.2), n), L)
 if "mirna" in which:     # hairpin.fa-like: 39..2354, mostly ~100
     rng = np.random.default_rng(10)
     ok &= run("hairpin-like log-normal around 100", np.clip(np.exp(rng.normal(np.log(100), 0.35, 8_000_000)), 39, 2354).astype(np.int64), 10)
