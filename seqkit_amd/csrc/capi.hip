@@ -106,6 +106,7 @@ skh::LaunchCfg cfg_for(const skh_ctx* ctx, uint64_t nrec, uint64_t total)
     // reads of about 100 bases and ragged 30-151-base reads gain 4-5 points with 6, where fewer of
     // a lane group's chunk slots hold data and a wavefront has less in flight per step.
     c.staged_steps = ctx->staged_steps ? ctx->staged_steps : mean_len < 128 ? 6 : (mean_len >= 192 && mean_len < 512) ? 3 : 2;
+    c.short_steps = ctx->short_steps;
     c.count_steps = ctx->count_steps;
     c.stats_steps = ctx->stats_steps;
     c.use_hint = ctx->use_hint;
@@ -187,6 +188,7 @@ int skh_init(int device, skh_ctx** out)
     c->use_hint = env_int("SKH_HINT", 1);
     c->staged = env_int("SKH_STAGED", -1);
     c->staged_steps = (uint32_t)env_int("SKH_STAGED_STEPS", 0);
+    c->short_steps = (uint32_t)env_int("SKH_SHORT_STEPS", 0);
     c->count_steps = (uint32_t)env_int("SKH_COUNT_STEPS", 0);
     c->stats_steps = (uint32_t)env_int("SKH_STATS_STEPS", 0);
     e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);

@@ -24,6 +24,7 @@ struct skh_ctx {
     int use_hint = 1;
     int staged = -1;         // -1: by mean record length
     uint32_t staged_steps = 0;
+    uint32_t short_steps = 0;
     uint32_t count_steps = 0;
     uint32_t stats_steps = 0;
 };

@@ -22,6 +22,7 @@ struct LaunchCfg {
     uint32_t n_cu;       // compute units of the device
     int staged;          // reverse, short records: 1 = LDS-staged kernel, 0 = direct (lane exchange) kernel
     uint32_t staged_steps;   // staged kernel: steps per wavefront (0 = default)
+    uint32_t short_steps;    // direct reverse kernel: steps per wavefront (0 = about 32 KiB of plane per workgroup)
     uint32_t count_steps;    // short count kernel: steps per wavefront (0 = default)
     uint32_t stats_steps;    // stats kernel: runs of chunks per workgroup (0 = default)
     int fuse_fastq;      // reverse: 1 = bases and qualities in one launch, 0 = one launch per plane

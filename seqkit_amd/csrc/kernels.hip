@@ -415,31 +415,39 @@ __device__ __forceinline__ void reverse_batch(const RevPlanes& P, const RevLds& 
 }
 
 // Short records: a group of 2^logG lanes per record, lane j takes chunks j, j+G, ...
-// Nothing crosses lanes, so any G gives the same bytes.
+// Nothing crosses lanes, so any G gives the same bytes.  The grid covers the batch once, in index
+// order: workgroup b serves the `steps` * 4 consecutive wavefront steps from b * steps * 4 on (with
+// fewer lanes per record than the host sized the grid for, a step holds more records and the last
+// workgroups find nothing left to do).
 template <bool COMP, bool FASTQ>
-__global__ __launch_bounds__(SKH_BLOCK) void k_reverse_short(RevPlanes P, uint64_t nrec, Table256 lut,
-                                                             int logG, BatchHint* __restrict__ hint)
+__global__ __launch_bounds__(SKH_BLOCK) void k_reverse_short(RevPlanes P, uint64_t nrec, Table256 lut, int logG_host,
+                                                             uint32_t steps, BatchHint* __restrict__ hint, int use_hint)
 {
     uint32_t* n_long = &hint->n_long;
     __shared__ RevLds L;
+    const uint32_t mean_short = hint->mean_short;
     rev_lds_init<COMP>(L, lut);
     constexpr int U = 3;
+    const int logG = hinted_logG<false>(logG_host, mean_short, use_hint);
     const uint32_t G = 1u << logG, j = threadIdx.x & (G - 1);
     const uint32_t lane = threadIdx.x & 63, GW = 64u >> logG, g = lane >> logG;
-    const uint64_t stride = (uint64_t)gridDim.x * (SKH_BLOCK / 64) * GW;
+    constexpr uint32_t WAVES = SKH_BLOCK / 64;
+    const uint64_t stride = (uint64_t)WAVES * GW;
     // the wavefront's first record; all its lanes run the same number of steps
-    uint64_t rec0 = ((uint64_t)xcd_remap(blockIdx.x, gridDim.x) * (SKH_BLOCK / 64) + (threadIdx.x >> 6)) * GW;
-    if (rec0 >= nrec) return;
+    uint64_t rec0 = ((uint64_t)blockIdx.x * steps * WAVES + (threadIdx.x >> 6)) * GW;
+    const uint64_t rec_stop = (uint64_t)(blockIdx.x + 1) * steps * WAVES * GW;
+    const uint64_t rec_end = rec_stop < nrec ? rec_stop : nrec;      // first record not served here
+    if (rec0 >= rec_end) return;
     WaveOffsets wo;
     wo.load(P.offs, nrec, P.total, rec0, GW, lane);
     while (true) {
         // the offsets of the next step are requested before this one is worked on
         const uint64_t next0 = rec0 + stride;
         WaveOffsets nwo;
-        if (next0 < nrec) nwo.load(P.offs, nrec, P.total, next0, GW, lane);
+        if (next0 < rec_end) nwo.load(P.offs, nrec, P.total, next0, GW, lane);
         const uint64_t rec = rec0 + g;
         const uint64_t sprev = wo.get(g, GW), s = wo.get(g + 1, GW), e = wo.get(g + 2, GW);
-        const uint64_t len = e - s;
+        const uint64_t len = rec < rec_end ? e - s : 0;
         if (len > SKH_LONG_T) {
             if (j == 0) atomicAdd(n_long, 1u);
         } else if (len != 0) {
@@ -451,7 +459,7 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_reverse_short(RevPlanes P, uint64
                 reverse_chunk_generic<COMP, FASTQ>(P.in, P.out, P.qin, P.qout, P.offs, rec, P.total,
                                                    o0 + 16ull * n_own, L.lut);
         }
-        if (next0 >= nrec) break;
+        if (next0 >= rec_end) break;
         rec0 = next0;
         wo = nwo;
     }
@@ -1791,9 +1799,16 @@ static hipError_t launch_reverse_t(const LaunchCfg& cfg, const uint8_t* in, uint
         hipLaunchKernelGGL((k_reverse_staged<COMP>), dim3((uint32_t)g1), dim3(SKH_BLOCK), 0, st, P.in, P.out, P.offs,
                            P.total, nrec, lut, cfg.logG, steps, hint, cfg.use_hint);
     } else {
-        const uint32_t g1 = grid_for(nrec, SKH_BLOCK >> cfg.logG, resident_cap(k_reverse_short<COMP, FASTQ>, cfg));
-        hipLaunchKernelGGL((k_reverse_short<COMP, FASTQ>), dim3(g1), dim3(SKH_BLOCK), 0, st, P, nrec, lut,
-                           cfg.logG, hint);
+        // up to 8 steps and about 128 KiB of the plane per workgroup (measured on records of 350 to 16000
+        // bases: 8 steps 1-2 points ahead of 2-4 up to 1000 bases, no difference beyond)
+        const uint64_t step_bytes = (uint64_t)(SKH_BLOCK >> cfg.logG) * (nrec ? total / nrec : 0) + 1;
+        uint32_t steps = cfg.short_steps ? cfg.short_steps : (uint32_t)(131072 / step_bytes);
+        steps = steps < 1 ? 1 : (steps > 8 ? 8 : steps);
+        const uint64_t per_block = (uint64_t)steps * (SKH_BLOCK >> cfg.logG);
+        const uint64_t g1 = (nrec + per_block - 1) / per_block;
+        if (g1 > 0x7fffffffull) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((k_reverse_short<COMP, FASTQ>), dim3((uint32_t)g1), dim3(SKH_BLOCK), 0, st, P, nrec, lut,
+                           cfg.logG, steps, hint, cfg.use_hint);
     }
     const uint64_t g2 = long_runs(total);
     if (g2 > 0x7fffffffull) return hipErrorInvalidValue;
