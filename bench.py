@@ -71,7 +71,7 @@ def measured_traffic(kernel):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=700, help="timed steps (default: a timed region of about one second)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--nrec", type=int, default=10_000_000, help="records per GPU (default: configs[1])")
     ap.add_argument("--read-len", type=int, default=150)
@@ -80,6 +80,9 @@ def parse():
     ap.add_argument("--no-e2e", action="store_true", help="skip the file-to-file run of the driver")
     ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configurations")
     ap.add_argument("--no-collective", action="store_true", help="skip the RCCL all-reduce of the stats totals (profiler passes)")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="N ranks on however many GPUs are visible (ranks share a GPU), gloo process group, no RCCL: "
+                         "exercises the N > 1 code path on a one-GPU machine; its numbers mean nothing")
     return ap.parse_args()
 
 
@@ -396,10 +399,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU"
+    if args.rehearse:
+        local %= torch.cuda.device_count()
+        args.no_collective = True
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     lib = seqkit_amd.load()          # fails loudly when the HIP library is missing
     ctx = lib.init(local)
