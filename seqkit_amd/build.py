@@ -39,6 +39,23 @@ def build_lib(force=False, verbose=False):
     return LIB
 
 
+LIB_CHECKED = os.path.join(PKG, "libseqkit_hip_checked.so")
+
+
+def build_lib_checked(force=False, verbose=False):
+    """The same library with SKH_STAGE_CHECK: the LDS-staged reverse kernel compares every stage buffer with
+    global memory after its hand-counted wait and the entry point reports mismatches.  Tests only."""
+    if not force and not _stale(LIB_CHECKED, LIB_DEPS):
+        return LIB_CHECKED
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DSKH_STAGE_CHECK",
+           "-I", os.path.join(ROOT, "include"), "-I", os.path.join(PKG, "csrc"),
+           "-Wall", "-Wno-unused-function", "-o", LIB_CHECKED] + LIB_SRCS + ["-ldl"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_CHECKED
+
+
 def build_cli(force=False, verbose=False):
     if not all(os.path.exists(s) for s in CLI_SRCS):
         return None
@@ -53,7 +70,11 @@ def build_cli(force=False, verbose=False):
 
 
 def build_all(force=False, verbose=False):
-    build_lib(force, verbose)
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(2) as pool:              # two independent hipcc runs
+        jobs = [pool.submit(build_lib, force, verbose), pool.submit(build_lib_checked, force, verbose)]
+        for j in jobs:
+            j.result()
     build_cli(force, verbose)
 
 

@@ -346,6 +346,15 @@ static int revcomp_impl(skh_ctx* ctx, const uint8_t* d_in, uint8_t* d_out, const
         if ((rc = slot_for(ctx, st, &slot))) return rc;
         HIP_TRY(skh::launch_reverse(cfg, d_in, d_out, d_qin, d_qout, d_offs, nrec, total,
                                     lut ? &t : nullptr, ctx->d_hints + slot, st));
+#ifdef SKH_STAGE_CHECK
+        // checked build (tests only): the staged kernel compared every stage buffer with global memory
+        skh::BatchHint h;
+        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipMemcpy(&h, ctx->d_hints + slot, sizeof h, hipMemcpyDeviceToHost));
+        if (h.pad[0] != 0)
+            return fail(SKH_EHIP, "staged reverse kernel: %s wavefront steps found their stage buffer incomplete",
+                        std::to_string(h.pad[0]).c_str());
+#endif
     } else {
         if (lut) HIP_TRY(skh::launch_map_plane(cfg, d_in, d_out, total, t, st));
         else HIP_TRY(hipMemcpyAsync(d_out, d_in, total, hipMemcpyDeviceToDevice, st));

@@ -654,6 +654,37 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_reverse_staged(const uint8_t* __r
         uint64_t a0, nst;
         stretch_range(rec0 ? L[0] : 0, e_last, padded, a0, nst);
 
+#ifdef SKH_STAGE_CHECK
+        // Checked build: what the hand-counted wait above promises -- this step's stretch and
+        // offsets slice are in LDS -- compared with global memory; mismatches are counted in the
+        // launch's scratch word and reported by the entry point.  LDS is sampled first, before
+        // anything else can wait for outstanding memory operations.
+        {
+            const uint32_t nb = nst < ST_BYTES ? (uint32_t)nst : ST_BYTES;
+            uint4 staged[ST_ROWS];
+#pragma unroll
+            for (uint32_t row = 0; row < ST_ROWS; row++) {
+                const uint32_t off = row * 1024 + lane * 16;
+                staged[row] = *reinterpret_cast<const uint4*>(slot + (off < nb ? off : 0));
+            }
+            const uint64_t ob = rec0 ? rec0 - 1 : 0;
+            const uint32_t nof = (uint32_t)(hi - ob) + 1;                 // offsets ob .. hi
+            const uint64_t staged_off0 = L[lane < nof ? lane : 0], staged_off1 = L[lane + 64 < nof ? lane + 64 : 0];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            uint32_t bad = 0;
+#pragma unroll
+            for (uint32_t row = 0; row < ST_ROWS; row++) {
+                const uint32_t off = row * 1024 + lane * 16;
+                if (off < nb) {
+                    const uint4 y = ld16(in + a0 + off);
+                    bad |= staged[row].x != y.x || staged[row].y != y.y || staged[row].z != y.z || staged[row].w != y.w;
+                }
+            }
+            if (lane < nof && ob + lane < nrec) bad |= staged_off0 != offs[ob + lane];
+            if (lane + 64 < nof && ob + lane + 64 < nrec) bad |= staged_off1 != offs[ob + lane + 64];
+            if (bad) atomicAdd(&hint->pad[0], 1u);
+        }
+#endif
         const uint64_t len = e - s;
         const bool is_long = len > SKH_LONG_T;
         if (is_long && j == 0) atomicAdd(n_long, 1u);
