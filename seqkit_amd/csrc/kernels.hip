@@ -465,6 +465,96 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_reverse_short(RevPlanes P, uint64
     }
 }
 
+// ---- in place --------------------------------------------------------------------------
+//
+// out == in: a byte may only be overwritten by a lane that has already read everything the
+// new bytes are made of.  A record [s, e) is taken as pairs of 16-byte windows at the same
+// distance from its two ends, [s + 16 i, +16) and [e - 16 i - 16, +16): one lane loads both and
+// stores each, reversed, in the other's place; it shares no byte with any other lane, whatever
+// the alignment of s and e (gfx950 global loads and stores take any byte address).  What is
+// left between the innermost pair (fewer than 32 bytes) goes to the lane of that pair, as
+// windows that overlap bytes the lane has loaded and not yet stored: two windows when at least
+// 16 bytes are left, otherwise one window that reaches back into the innermost pair.
+// Overlapping stores carry the same, final bytes, so their order does not matter.  Records
+// shorter than 16 bytes are swapped byte by byte.
+
+__device__ __forceinline__ void stu16(uint8_t* p, uint4 v)      // any byte address
+{
+    __builtin_memcpy(p, &v, 16);
+}
+
+template <bool COMP>
+__device__ __forceinline__ uint4 reversed_mapped(uint4 v, const uint8_t* s_lut)
+{
+    v = reverse16(v);
+    return COMP ? map16(v, s_lut) : v;
+}
+
+// The middle [m0, m0 + M) of a record, 0 < M < 32, between windows the caller has loaded but not
+// stored yet (or, with M >= 16, on its own).  load() before the caller's stores, store() after.
+template <bool COMP>
+struct MiddleInPlace {
+    uint4 x, y;
+    __device__ __forceinline__ void load(const uint8_t* p, uint64_t m0, uint32_t M)
+    {
+        x = ldu16(p + m0);                            // M < 16: reaches into the back window of the innermost pair
+        if (M >= 16) y = ldu16(p + m0 + M - 16);
+    }
+    __device__ __forceinline__ void store(uint8_t* p, uint64_t m0, uint32_t M, const uint8_t* s_lut) const
+    {
+        // [m0 + M - 16, m0 + M) is the mirror image of [m0, m0 + 16)
+        stu16(p + m0 + M - 16, reversed_mapped<COMP>(x, s_lut));
+        if (M >= 16) stu16(p + m0, reversed_mapped<COMP>(y, s_lut));
+    }
+};
+
+// [a, b) reversed byte by byte (a handful of bytes)
+template <bool COMP>
+__device__ __forceinline__ void reverse_bytes_inplace(uint8_t* p, uint64_t a, uint64_t b, const uint8_t* s_lut)
+{
+    while (b - a >= 2) {
+        b--;
+        const uint8_t x = p[a], y = p[b];
+        p[a] = COMP ? s_lut[y] : y;
+        p[b] = COMP ? s_lut[x] : x;
+        a++;
+    }
+    if (COMP && b - a == 1) p[a] = s_lut[p[a]];
+}
+
+// One record of at most LONG_T bytes by its group of G lanes: lane j takes the window pairs
+// j, j + G, ...
+template <bool COMP>
+__device__ __forceinline__ void reverse_record_inplace(uint8_t* p, uint64_t s, uint64_t e, uint32_t j, uint32_t G,
+                                                       const uint8_t* s_lut)
+{
+    const uint64_t len = e - s;
+    if (len >= 16) {
+        const uint32_t n = (uint32_t)len >> 5, M = (uint32_t)len & 31u;       // pairs, bytes between them
+        const uint64_t m0 = s + 16ull * n;
+        if (n == 0) {
+            if (j == 0) {
+                MiddleInPlace<COMP> mid;
+                mid.load(p, m0, M);
+                mid.store(p, m0, M, s_lut);
+            }
+        } else {
+            for (uint32_t i = j; i < n; i += G) {
+                const uint64_t f = s + 16ull * i, b = e - 16ull * i - 16;
+                const bool inner = i == n - 1 && M != 0;
+                const uint4 F = ldu16(p + f), B = ldu16(p + b);
+                MiddleInPlace<COMP> mid;
+                if (inner) mid.load(p, m0, M);
+                stu16(p + f, reversed_mapped<COMP>(B, s_lut));
+                stu16(p + b, reversed_mapped<COMP>(F, s_lut));
+                if (inner) mid.store(p, m0, M, s_lut);
+            }
+        }
+    } else if (len != 0 && j == 0) {
+        reverse_bytes_inplace<COMP>(p, s, e, s_lut);
+    }
+}
+
 // ---- short records, staged form -------------------------------------------------------------
 //
 // The GW consecutive records a wavefront serves in one step are one contiguous stretch of the
@@ -540,7 +630,7 @@ __device__ __forceinline__ uint4 lds_window_reversed(const uint8_t* slot, uint32
                       __builtin_amdgcn_perm(V2, V1, sel), __builtin_amdgcn_perm(V1, V0, sel));
 }
 
-template <bool COMP>
+template <bool COMP, bool INPLACE>
 __global__ __launch_bounds__(SKH_BLOCK) void k_reverse_staged(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
                                                               const uint64_t* __restrict__ offs, uint64_t total,
                                                               uint64_t nrec, Table256 lut, int logG_host, uint32_t steps,
@@ -580,7 +670,8 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_reverse_staged(const uint8_t* __r
         r0 = r0 < rec_end ? r0 : rec_first;
         const uint64_t hi = r0 + GW < rec_end ? r0 + GW : rec_end;
         Bounds bd;
-        bd.first = r0 ? coffs[r0 - 1] : 0;
+        // (in place the record before the step supplies nothing: the stretch starts at the step's own records)
+        bd.first = INPLACE ? coffs[r0] : (r0 ? coffs[r0 - 1] : 0);
         bd.last = coffs[hi];
         return bd;
     };
@@ -592,7 +683,8 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_reverse_staged(const uint8_t* __r
         uint64_t a0, n;
         stretch_range(bd.first, bd.last, padded, a0, n);
         const uint32_t nb = n < ST_BYTES ? (uint32_t)n : ST_BYTES;
-        const uint32_t base = lds_addr_of(&S.bytes[wave][b][0]);
+        const uint32_t base = __builtin_amdgcn_readfirstlane(lds_addr_of(&S.bytes[wave][b][0]));
+        const uint32_t obase = __builtin_amdgcn_readfirstlane(lds_addr_of(&S.offs[wave][b][0]));
 #pragma unroll
         for (uint32_t row = 0; row < ST_ROWS; row++) {
             // lanes past the stretch re-read its last chunk: no branch, constant load count
@@ -606,7 +698,7 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_reverse_staged(const uint8_t* __r
         if (lane < npairs) {
             uint64_t p = ob + 2ull * lane;
             p = p < nrec ? p : nrec - 1;
-            load_to_lds16(offs + p, lds_addr_of(&S.offs[wave][b][0]));
+            load_to_lds16(offs + p, obase);
         }
     };
 
@@ -652,14 +744,14 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_reverse_staged(const uint8_t* __r
         const uint64_t hi = rec0 + GW < rec_end ? rec0 + GW : rec_end;
         const uint64_t s_first = L[i0], e_last = hi == nrec ? total : L[i0 + (uint32_t)(hi - rec0)];
         uint64_t a0, nst;
-        stretch_range(rec0 ? L[0] : 0, e_last, padded, a0, nst);
+        stretch_range(INPLACE ? s_first : (rec0 ? L[0] : 0), e_last, padded, a0, nst);
 
 #ifdef SKH_STAGE_CHECK
         // Checked build: what the hand-counted wait above promises -- this step's stretch and
         // offsets slice are in LDS -- compared with global memory; mismatches are counted in the
         // launch's scratch word and reported by the entry point.  LDS is sampled first, before
         // anything else can wait for outstanding memory operations.
-        {
+        if (!INPLACE) {              // (in place the edges of a stretch are rewritten by the neighbours meanwhile)
             const uint32_t nb = nst < ST_BYTES ? (uint32_t)nst : ST_BYTES;
             uint4 staged[ST_ROWS];
 #pragma unroll
@@ -696,12 +788,39 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_reverse_staged(const uint8_t* __r
         // is too short to supply its first bytes as one window; bit 1 = the chunk straddling
         // the plane end
         uint32_t bytewise = 0;
-        if (work && j == 0) {
+        if (!INPLACE && work && j == 0) {
             if (n_own != 0 && sp != 0 && !(sprev <= o0 && sprev + sp >= 16 && e + sp <= padded)) bytewise |= 1u;
             if (e == total && (e & 15) != 0) bytewise |= 2u;
         }
         constexpr uint32_t IT = 3;                   // chunks per lane the coalesced form holds
-        if (nst > ST_BYTES) {
+        // In place (out == in) the step may write the bytes of its own records only: the aligned
+        // chunks that lie wholly inside [s_first, e_last) as below, and what is left at either end
+        // inside two misaligned 16-byte stores -- the first 16 bytes of the step's first record and
+        // the last 16 of its last record, each the mirror image of the record's other end, taken
+        // from the stage before anything is written back into it (what these stores overlap of the
+        // chunks has the same, final bytes).  A step that does not fit that picture (an edge record
+        // shorter than 16 bytes, a head chunk the record before cannot supply as one window, a
+        // stretch larger than the stage) goes to the window-pair form, which needs nothing but each
+        // record's own bytes in global memory.
+        const bool first_rec = INPLACE && work && s == s_first;          // the step's first non-empty record
+        const bool last_rec = INPLACE && work && e == e_last;            // ... and its last
+        bool pairs = false;
+        if (INPLACE && work) {
+            if (!first_rec && n_own != 0 && sp != 0 && !(sprev <= o0 && sprev + sp >= 16 && e + sp <= padded)) pairs = true;
+            if (len < 16 && ((first_rec && (s & 15) != 0) || (last_rec && (e & 15) != 0))) pairs = true;
+        }
+        const bool use_pairs = INPLACE && (nst > ST_BYTES || __any(pairs));
+        const bool edge_h = !use_pairs && first_rec && j == 0 && (s & 15) != 0,
+                   edge_t = !use_pairs && last_rec && j == 0 && (e & 15) != 0;
+        uint4 EH = make_uint4(0, 0, 0, 0), ET = EH;
+        if (INPLACE) {
+            if (edge_h) EH = lds_window_reversed(slot, (uint32_t)(e - 16 - a0));
+            if (edge_t) ET = lds_window_reversed(slot, (uint32_t)(s - a0));
+            if (COMP && (edge_h || edge_t)) { EH = map16(EH, S.tab.lut); ET = map16(ET, S.tab.lut); }
+        }
+        if (use_pairs) {
+            reverse_record_inplace<COMP>(out, work ? s : 0, work ? e : 0, j, G, S.tab.lut);
+        } else if (nst > ST_BYTES) {
             // stretch larger than the stage (an outlier among short records): every window
             // straight from global memory with one misaligned load -- slower, few registers
             const uint64_t q0 = s + e - 16 - o0;
@@ -719,6 +838,7 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_reverse_staged(const uint8_t* __r
             const uint32_t lq0 = (uint32_t)(s + e - 16 - o0 - a0);      // window of chunk 0 in the slot
             for (uint32_t k = j; k < n_own; k += G) {
                 if (k == 0 && (bytewise & 1u)) continue;
+                if (INPLACE && k == 0 && first_rec && sp != 0) continue;  // not wholly the step's: see the edge stores
                 uint4 r = lds_window_reversed(slot, lq0 - 16 * k);
                 if (k == 0 && sp != 0) {
                     // the previous record supplies bytes [0, sp) of this chunk
@@ -742,7 +862,7 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_reverse_staged(const uint8_t* __r
                 const uint32_t k = j + it * G;
                 if (k < n_own && !(k == 0 && (bytewise & 1u))) {
                     uint4 v = lds_window_reversed(slot, lq0 - 16 * k);
-                    if (k == 0 && sp != 0) {
+                    if (k == 0 && sp != 0 && !first_rec) {
                         const uint32_t lqp = (uint32_t)(sprev + s - 16 - o0 - a0);
                         v = select16(S.tab.low[sp], lds_window_reversed(slot, lqp), v);
                     }
@@ -761,17 +881,22 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_reverse_staged(const uint8_t* __r
                 const uint32_t k = j + it * G;
                 if (k < n_own) *reinterpret_cast<uint4*>(slot + w0 + 16 * k) = r[it];
             }
-            const uint32_t c0 = __builtin_amdgcn_readfirstlane((uint32_t)((s_first & ~15ull) - a0)),
+            // in place the rows hold only the chunks that lie wholly inside the step's records
+            const uint32_t c0 = __builtin_amdgcn_readfirstlane((uint32_t)(((INPLACE ? s_first + 15 : s_first) & ~15ull) - a0)),
                            c1 = __builtin_amdgcn_readfirstlane((uint32_t)((e_last & ~15ull) - a0));
 #pragma unroll
             for (uint32_t row = 0; row < ST_ROWS; row++) {
-                if (row * 1024 < c1 && (row + 1) * 1024 > c0) {      // wave-uniform: some lane of the row stores
+                if (c0 < c1 && row * 1024 < c1 && (row + 1) * 1024 > c0) {   // wave-uniform: some lane of the row stores
                     const uint32_t c = row * 1024 + lane * 16;
                     if (c >= c0 && c < c1)
                         *reinterpret_cast<uint4*>(out + a0 + c) = *reinterpret_cast<const uint4*>(slot + c);
                     rows_stored++;
                 }
             }
+        }
+        if (INPLACE) {
+            if (edge_h) stu16(out + s, EH);
+            if (edge_t) stu16(out + e - 16, ET);
         }
 #pragma unroll 1
         while (bytewise) {
@@ -815,65 +940,9 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_reverse_tiles(RevPlanes P, uint64
     });
 }
 
-// ---- in place --------------------------------------------------------------------------
-//
-// out == in: a byte may only be overwritten by a lane that has already read everything the
-// new bytes are made of.  A record [s, e) is taken as pairs of 16-byte windows at the same
-// distance from its two ends, [s + 16 i, +16) and [e - 16 i - 16, +16): one lane loads both and
-// stores each, reversed, in the other's place; it shares no byte with any other lane, whatever
-// the alignment of s and e (gfx950 global loads and stores take any byte address).  What is
-// left between the innermost pair (fewer than 32 bytes) goes to the lane of that pair, as
-// windows that overlap bytes the lane has loaded and not yet stored: two windows when at least
-// 16 bytes are left, otherwise one window that reaches back into the innermost pair.
-// Overlapping stores carry the same, final bytes, so their order does not matter.  Records
-// shorter than 16 bytes are swapped byte by byte.
+// ---- in place: kernels (the window-pair helpers are defined ahead of the staged kernel) ------
 
-__device__ __forceinline__ void stu16(uint8_t* p, uint4 v)      // any byte address
-{
-    __builtin_memcpy(p, &v, 16);
-}
-
-template <bool COMP>
-__device__ __forceinline__ uint4 reversed_mapped(uint4 v, const uint8_t* s_lut)
-{
-    v = reverse16(v);
-    return COMP ? map16(v, s_lut) : v;
-}
-
-// The middle [m0, m0 + M) of a record, 0 < M < 32, between windows the caller has loaded but not
-// stored yet (or, with M >= 16, on its own).  load() before the caller's stores, store() after.
-template <bool COMP>
-struct MiddleInPlace {
-    uint4 x, y;
-    __device__ __forceinline__ void load(const uint8_t* p, uint64_t m0, uint32_t M)
-    {
-        x = ldu16(p + m0);                            // M < 16: reaches into the back window of the innermost pair
-        if (M >= 16) y = ldu16(p + m0 + M - 16);
-    }
-    __device__ __forceinline__ void store(uint8_t* p, uint64_t m0, uint32_t M, const uint8_t* s_lut) const
-    {
-        // [m0 + M - 16, m0 + M) is the mirror image of [m0, m0 + 16)
-        stu16(p + m0 + M - 16, reversed_mapped<COMP>(x, s_lut));
-        if (M >= 16) stu16(p + m0, reversed_mapped<COMP>(y, s_lut));
-    }
-};
-
-// [a, b) reversed byte by byte (a handful of bytes)
-template <bool COMP>
-__device__ __forceinline__ void reverse_bytes_inplace(uint8_t* p, uint64_t a, uint64_t b, const uint8_t* s_lut)
-{
-    while (b - a >= 2) {
-        b--;
-        const uint8_t x = p[a], y = p[b];
-        p[a] = COMP ? s_lut[y] : y;
-        p[b] = COMP ? s_lut[x] : x;
-        a++;
-    }
-    if (COMP && b - a == 1) p[a] = s_lut[p[a]];
-}
-
-// Records of at most LONG_T bytes: a group of 2^logG lanes per record, lane j takes the window
-// pairs j, j + G, ...
+// Records of at most LONG_T bytes: a group of 2^logG lanes per record.
 template <bool COMP>
 __global__ __launch_bounds__(SKH_BLOCK) void k_reverse_inplace_short(uint8_t* __restrict__ p,
                                                                      const uint64_t* __restrict__ offs, uint64_t total,
@@ -900,29 +969,8 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_reverse_inplace_short(uint8_t* __
         const uint64_t len = e - s;
         if (len > SKH_LONG_T) {
             if (j == 0) atomicAdd(n_long, 1u);
-        } else if (len >= 16) {
-            const uint32_t n = (uint32_t)len >> 5, M = (uint32_t)len & 31u;       // pairs, bytes between them
-            const uint64_t m0 = s + 16ull * n;
-            if (n == 0) {
-                if (j == 0) {
-                    MiddleInPlace<COMP> mid;
-                    mid.load(p, m0, M);
-                    mid.store(p, m0, M, L.lut);
-                }
-            } else {
-                for (uint32_t i = j; i < n; i += G) {
-                    const uint64_t f = s + 16ull * i, b = e - 16ull * i - 16;
-                    const bool inner = i == n - 1 && M != 0;
-                    const uint4 F = ldu16(p + f), B = ldu16(p + b);
-                    MiddleInPlace<COMP> mid;
-                    if (inner) mid.load(p, m0, M);
-                    stu16(p + f, reversed_mapped<COMP>(B, L.lut));
-                    stu16(p + b, reversed_mapped<COMP>(F, L.lut));
-                    if (inner) mid.store(p, m0, M, L.lut);
-                }
-            }
-        } else if (len != 0 && j == 0) {
-            reverse_bytes_inplace<COMP>(p, s, e, L.lut);
+        } else {
+            reverse_record_inplace<COMP>(p, s, e, j, G, L.lut);
         }
         if (next0 >= nrec) break;
         rec0 = next0;
@@ -1827,7 +1875,7 @@ static hipError_t launch_reverse_t(const LaunchCfg& cfg, const uint8_t* in, uint
         const uint64_t per_block = (uint64_t)steps * (SKH_BLOCK >> cfg.logG);
         const uint64_t g1 = (nrec + per_block - 1) / per_block;
         if (g1 > 0x7fffffffull) return hipErrorInvalidValue;
-        hipLaunchKernelGGL((k_reverse_staged<COMP>), dim3((uint32_t)g1), dim3(SKH_BLOCK), 0, st, P.in, P.out, P.offs,
+        hipLaunchKernelGGL((k_reverse_staged<COMP, false>), dim3((uint32_t)g1), dim3(SKH_BLOCK), 0, st, P.in, P.out, P.offs,
                            P.total, nrec, lut, cfg.logG, steps, hint, cfg.use_hint);
     } else {
         // up to 8 steps and about 128 KiB of the plane per workgroup (measured on records of 350 to 16000
@@ -1898,9 +1946,19 @@ template <bool COMP>
 static hipError_t launch_reverse_inplace_t(const LaunchCfg& cfg, uint8_t* plane, const uint64_t* offs, uint64_t nrec,
                                            uint64_t total, const Table256& lut, BatchHint* hint, hipStream_t st)
 {
-    const uint32_t g1 = grid_for(nrec, SKH_BLOCK >> cfg.logG, resident_cap(k_reverse_inplace_short<COMP>, cfg));
-    hipLaunchKernelGGL((k_reverse_inplace_short<COMP>), dim3(g1), dim3(SKH_BLOCK), 0, st, plane, offs, total, nrec, lut,
-                       cfg.logG, hint, cfg.use_hint);
+    if (cfg.staged) {
+        // short reads: the LDS-staged kernel with one plane (aligned row loads and stores)
+        const uint32_t steps = cfg.staged_steps ? cfg.staged_steps : 2;
+        const uint64_t per_block = (uint64_t)steps * (SKH_BLOCK >> cfg.logG);
+        const uint64_t g1 = (nrec + per_block - 1) / per_block;
+        if (g1 > 0x7fffffffull) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((k_reverse_staged<COMP, true>), dim3((uint32_t)g1), dim3(SKH_BLOCK), 0, st, plane, plane, offs,
+                           total, nrec, lut, cfg.logG, steps, hint, cfg.use_hint);
+    } else {
+        const uint32_t g1 = grid_for(nrec, SKH_BLOCK >> cfg.logG, resident_cap(k_reverse_inplace_short<COMP>, cfg));
+        hipLaunchKernelGGL((k_reverse_inplace_short<COMP>), dim3(g1), dim3(SKH_BLOCK), 0, st, plane, offs, total, nrec, lut,
+                           cfg.logG, hint, cfg.use_hint);
+    }
     const uint64_t g2 = long_runs(total);
     if (g2 > 0x7fffffffull) return hipErrorInvalidValue;
     hipLaunchKernelGGL((k_reverse_inplace_long<COMP>), dim3((uint32_t)g2), dim3(SKH_BLOCK), 0, st, plane, offs, total,

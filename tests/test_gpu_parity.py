@@ -74,6 +74,9 @@ def length_cases():
         # lanes per record from the sampled short records, the long-record kernels walk the offsets
         "reads_plus_contigs": np.concatenate([np.full(1500, 150), [2_000_003], np.full(1500, 150), [1_500_000, 151],
                                               rng.integers(30, 152, 2000), [40000]]),
+        # whole wavefront steps of empty or one-byte records between reads: steps that store nothing
+        "empty_runs": np.concatenate([np.zeros(100, np.int64), np.full(50, 150), np.zeros(64, np.int64), np.ones(40, np.int64),
+                                      np.full(100, 150), np.zeros(300, np.int64), [7], np.zeros(16, np.int64)]),
         "long_run_of_longs": np.concatenate([rng.integers(33000, 70000, 40), [12], rng.integers(100, 200, 600)]),
     }
 
@@ -135,9 +138,16 @@ def run_revcomp_inplace(lib, ctx, seq, qual, offs, lut, do_reverse):
     return d_seq.cpu().numpy(), d_qual.cpu().numpy() if qual is not None else None
 
 
-@pytest.fixture(scope="module")
-def ctx_default(lib):
+# in place: the LDS-staged kernel with one plane (short reads) or window pairs per lane; both for every case
+@pytest.fixture(scope="module", params=["auto", "staged", "pairs"])
+def ctx_default(lib, request):
+    old = os.environ.get("SKH_STAGED")
+    if request.param != "auto":
+        os.environ["SKH_STAGED"] = "1" if request.param == "staged" else "0"
     c = lib.init(0)
+    os.environ.pop("SKH_STAGED", None)
+    if old is not None:
+        os.environ["SKH_STAGED"] = old
     yield c
     lib.skh_destroy(c)
 

@@ -33,12 +33,14 @@ def lengths_of(shape):
         "trimmed": rng.integers(30, 152, 300_000),
         "ragged0_300": rng.integers(0, 301, 200_000),            # overflowing stretches, empty records
         "tiny": rng.integers(0, 21, 400_000),
+        "empty_runs": np.concatenate([np.zeros(4096, np.int64), np.full(50_000, 150), np.zeros(6400, np.int64),
+                                      np.ones(4000, np.int64), np.full(100_000, 150), np.zeros(30_000, np.int64), [7]]),
         "with_long": np.concatenate([np.full(50_000, 150), [100_000, 3, 1 << 20], np.full(50_000, 150)]),
     }[shape]
 
 
 @pytest.mark.parametrize("steps", ["1", "2", "6"])
-@pytest.mark.parametrize("shape", ["reads150", "reads100", "reads250", "trimmed", "ragged0_300", "tiny", "with_long"])
+@pytest.mark.parametrize("shape", ["reads150", "reads100", "reads250", "trimmed", "ragged0_300", "tiny", "empty_runs", "with_long"])
 def test_stage_buffers_complete(checked, oracle_lib, shape, steps, monkeypatch):
     import torch
     monkeypatch.setenv("SKH_STAGED", "1")
