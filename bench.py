@@ -494,6 +494,12 @@ def main():
         assert ok_stats, stats
         lib.skh_comm_destroy(comm)
 
+    # the same reverse-complement with one plane (skh_revcomp_inplace_dev), outside the timed steps
+    work = seq.clone()
+    inplace_ms = b.time_ms(lambda: lib.check(lib.skh_revcomp_inplace_dev(ctx, p(work), None, p(offs), nrec, total, b.lut, 1, sp)),
+                           reps=10)
+    del work
+
     ok = True
     if not args.no_verify:
         # size-independent checks at full size: revcomp is an involution; counts add up
@@ -547,6 +553,7 @@ def main():
                 "revcomp_bases": figure(rev_ms, rev_bytes, total),
                 "reverse_quals": figure(qual_ms, rev_bytes, total),
                 "seq_r_p_fastq": figure(rev_ms + qual_ms, 2 * rev_bytes, total),
+                "revcomp_bases_in_place": figure(inplace_ms, rev_bytes, total),
                 "count4": figure(cnt_ms, cnt_bytes, total),
                 "stats": figure(stats_ms, st_bytes, total),
             },

@@ -105,9 +105,10 @@ int skh_revcomp_fastq_dev(skh_ctx *ctx, const uint8_t *d_seq_in, uint8_t *d_seq_
 /* The same with ONE plane per kind, overwritten: what the reference's methods do to a record
  * ((*Seq).ReverseInplace reverses Seq.Seq and Seq.Qual where they lie, ComplementInplace maps
  * Seq.Seq where it lies; call sites seqkit/cmd/seq.go:188,194).  d_qual may be NULL; it is reversed
- * with the bases (do_reverse) and otherwise left alone.  Costs half the device memory of the
- * out-of-place form and the same traffic; the out-of-place form is the faster one on reads of a
- * few hundred bases, where its stores are whole aligned rows. */
+ * with the bases (do_reverse) and otherwise left alone.  Half the device memory of the
+ * out-of-place form, the same traffic, and the same speed on fixed-length reads; ragged short
+ * reads run about a tenth slower than out of place (the ends of a wavefront's records leave
+ * as misaligned stores). */
 int skh_revcomp_inplace_dev(skh_ctx *ctx, uint8_t *d_seq, uint8_t *d_qual,
                             const uint64_t *d_offsets, uint64_t nrec, uint64_t total_bytes,
                             const uint8_t *lut, int do_reverse, void *stream);
