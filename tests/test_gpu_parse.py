@@ -19,7 +19,7 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 class OraRecord(C.Structure):
     _fields_ = [("name", C.POINTER(C.c_uint8)), ("name_len", C.c_size_t), ("id_len", C.c_size_t),
-                ("seq", C.POINTER(C.c_uint8)), ("seq_len", C.c_size_t),
+                ("id", C.POINTER(C.c_uint8)), ("seq", C.POINTER(C.c_uint8)), ("seq_len", C.c_size_t),
                 ("qual", C.POINTER(C.c_uint8)), ("qual_len", C.c_size_t)]
 
 
