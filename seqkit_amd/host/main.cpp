@@ -2,6 +2,8 @@
 // reference commands on the hot path (flag names and letters as registered in
 // seqkit/cmd/root.go:65-72, seq.go:291-306, fx2tab.go:157-164, stat.go:292-294, subseq.go:549-564,
 // convert.go:280-291).
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -105,8 +107,22 @@ int usage()
 
 }  // namespace
 
+namespace {
+// SKH_TIMING=1: how long main() ran, on stderr; what the process took beyond that is the dynamic loader
+// before main and the HIP runtime's own tear-down after it
+struct MainTimer {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    ~MainTimer()
+    {
+        if (getenv("SKH_TIMING"))
+            fprintf(stderr, "[timing] main %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    }
+};
+}  // namespace
+
 int main(int argc, char** argv)
 {
+    MainTimer main_timer;
     if (argc < 2) return usage();
     const std::string cmd = argv[1];
     const bool is_seq = cmd == "seq", is_fx = cmd == "fx2tab", is_st = cmd == "stats" || cmd == "stat",
