@@ -62,7 +62,8 @@ def measured_traffic(kernel):
             with open(os.path.join(pdir, name)) as fh:
                 doc = json.load(fh)
             if doc.get("kernels_sha16") == kernels_sha16():
-                best = doc["kernels"][kernel]["hbm_bytes"]
+                by_name = {k.replace(" ", ""): v for k, v in doc["kernels"].items()}     # demanglers differ in spacing
+                best = by_name[kernel.replace(" ", "")]["hbm_bytes"]
         except (OSError, KeyError, ValueError):
             pass
     return best
@@ -540,10 +541,10 @@ def main():
                                    "(reverse-complement + quality reversal) then fx2tab -g -B AGCT counts, "
                                    "resident in HBM" % (nrec, L),
                        "records_per_gpu": nrec, "read_len": L, "parallelism": "records sharded, %d rank(s)" % world},
-            "roofline": {"bound": "hbm", "kernel": "skh::k_reverse_staged<true> (bases: reverse + complement)",
+            "roofline": {"bound": "hbm", "kernel": "skh::k_reverse_staged<true, false> (bases: reverse + complement, two planes)",
                          "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": measured_traffic("skh::k_reverse_staged<true>")
+                         "traffic": measured_traffic("skh::k_reverse_staged<true, false>")
                          if (nrec, L) == (10_000_000, 150) else None,
                          "traffic_source": "committed rocprofv3 --pmc passes under profiles/ whose kernels.hip hash (%s) "
                                            "matches this tree; null otherwise" % kernels_sha16(),
