@@ -129,6 +129,15 @@ __device__ __forceinline__ void copy16(uint8_t* __restrict__ dst, const uint8_t*
     __builtin_memcpy(dst, &v, 16);
 }
 
+// Tables of a record, read by the first lane of its group and handed to the others by cross-lane
+// reads: the L1 counts every lane of a load, also when all of them ask for the same address, and
+// these kernels run at its access rate.
+__device__ __forceinline__ uint64_t from_lane64(uint64_t v, uint32_t src_lane)
+{
+    return ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(v >> 32), (int)src_lane) << 32) |
+           (uint32_t)__shfl((int)(uint32_t)v, (int)src_lane);
+}
+
 template <uint32_t G>
 __device__ __forceinline__ void copy_plain(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, uint64_t n, uint32_t j)
 {
@@ -173,14 +182,24 @@ __global__ __launch_bounds__(FB) void k_fmt_write(const FormatSeqArgs a, const u
     constexpr uint32_t G = 16;
     if (*total > out_capacity) return;
     const uint32_t j = threadIdx.x & (G - 1);
+    const uint32_t leader = (threadIdx.x & 63) & ~(G - 1);
     for (uint64_t r = ((uint64_t)blockIdx.x * FB + threadIdx.x) / G; r < a.nrec; r += (uint64_t)gridDim.x * (FB / G)) {
-        if (size[r] == 0) continue;
-        uint8_t* o = out + pos[r];
-        const uint64_t s = a.offsets[r], len = a.offsets[r + 1] - s;
+        uint64_t m_size = 0, m_pos = 0, m_s = 0, m_e = 0, m_name = 0;
+        uint32_t m_nl = 0;
+        if (j == 0) {
+            m_size = size[r];
+            if (m_size != 0) {
+                m_pos = pos[r]; m_s = a.offsets[r]; m_e = a.offsets[r + 1];
+                if (a.print_name) { m_nl = shown_name[r]; m_name = a.name_pos[r]; }
+            }
+        }
+        if (from_lane64(m_size, leader) == 0) continue;
+        uint8_t* o = out + from_lane64(m_pos, leader);
+        const uint64_t s = from_lane64(m_s, leader), len = from_lane64(m_e, leader) - s;
         if (a.print_name) {
-            const uint32_t nl = shown_name[r];
+            const uint32_t nl = __shfl(m_nl, leader);
             if (a.print_seq) { if (j == 0) *o = (a.empty_fasta && len == 0) ? (uint8_t)'>' : a.mark; o++; }
-            copy_plain<G>(o, a.text + a.name_pos[r], nl, j);
+            copy_plain<G>(o, a.text + from_lane64(m_name, leader), nl, j);
             if (j == 0) o[nl] = '\n';
             o += nl + 1;
         }
@@ -381,11 +400,15 @@ __global__ __launch_bounds__(FB) void k_tab_write(const FormatTabArgs a, const u
     constexpr uint32_t G = 16;
     if (*total > out_capacity) return;
     const uint32_t j = threadIdx.x & (G - 1);
+    const uint32_t leader = (threadIdx.x & 63) & ~(G - 1);
     for (uint64_t r = ((uint64_t)blockIdx.x * FB + threadIdx.x) / G; r < a.nrec; r += (uint64_t)gridDim.x * (FB / G)) {
-        uint8_t* o = out + pos[r];
-        const uint64_t s = a.offsets[r], len = a.offsets[r + 1] - s;
-        const uint32_t nl = shown_name[r];
-        copy_plain<G>(o, a.text + a.name_pos[r], nl, j);
+        uint64_t m_pos = 0, m_s = 0, m_e = 0, m_name = 0;
+        uint32_t m_nl = 0;
+        if (j == 0) { m_pos = pos[r]; m_s = a.offsets[r]; m_e = a.offsets[r + 1]; m_nl = shown_name[r]; m_name = a.name_pos[r]; }
+        uint8_t* o = out + from_lane64(m_pos, leader);
+        const uint64_t s = from_lane64(m_s, leader), len = from_lane64(m_e, leader) - s;
+        const uint32_t nl = __shfl(m_nl, leader);
+        copy_plain<G>(o, a.text + from_lane64(m_name, leader), nl, j);
         if (j == 0) o[nl] = '\t';
         o += nl + 1;
         const bool is_long = len > SKH_LONG_T;           // bases and qualities: k_tab_write_long
