@@ -55,7 +55,9 @@ def run(name, lengths, seed):
         "stats": (lambda: lib.skh_stats_dev(ctx, p(seq), p(offs), nrec, total, gap, p(stats), sp), total + 8 * nrec),
     }
     print("== %s: %d records, %.2f Gbases, max %d" % (name, nrec, total / 1e9, lengths.max()))
+    only = os.environ.get("OPS")
     for op, (fn, nbytes) in ops.items():
+        if only and op not in only.split(","): continue
         for _ in range(2): fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(st)
