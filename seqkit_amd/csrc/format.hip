@@ -138,85 +138,194 @@ __device__ __forceinline__ uint64_t from_lane64(uint64_t v, uint32_t src_lane)
            (uint32_t)__shfl((int)(uint32_t)v, (int)src_lane);
 }
 
-template <uint32_t G>
-__device__ __forceinline__ void copy_plain(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, uint64_t n, uint32_t j)
+// p / width for the positions inside one record.  Div64: plain division.  Div32: records of the LDS-staged
+// writer are shorter than 8 KiB, where one multiplication by ceil(2^32 / width) is exact
+// (p * (magic * width - 2^32) < 2^32); a width beyond that never divides anything but to 0.
+struct Div64 {
+    uint32_t width;
+    __device__ __forceinline__ uint64_t operator()(uint64_t p) const { return p / width; }
+};
+struct Div32 {
+    uint32_t width, magic;
+    __device__ __forceinline__ explicit Div32(uint32_t w)
+        : width(w), magic(w < 2 || w > 8192 ? 0u : (uint32_t)((0x100000000ull + w - 1) / w)) {}
+    __device__ __forceinline__ uint32_t operator()(uint32_t p) const { return width == 1 ? p : __umulhi(p, magic); }
+};
+
+template <uint32_t G, typename T>
+__device__ __forceinline__ void copy_plain(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, T n, uint32_t j)
 {
-    for (uint64_t p = (uint64_t)j * 16; p < n; p += G * 16) {
+    for (T p = (T)j * 16; p < n; p += G * 16) {
         if (p + 16 <= n) copy16(dst + p, src + p);
         else if (n >= 16) copy16(dst + n - 16, src + n - 16);     // the last 16 bytes again: same values, no byte loop
-        else for (uint64_t k = p; k < n; k++) dst[k] = src[k];
+        else for (T k = p; k < n; k++) dst[k] = src[k];
     }
 }
 
 // src[0..n) with a '\n' after every `width` bytes except after the last chunk
-template <uint32_t G>
-__device__ __forceinline__ void copy_wrapped(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, uint64_t n,
-                                             uint32_t width, uint32_t j)
+template <uint32_t G, typename T, typename DIV>
+__device__ __forceinline__ void copy_wrapped(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, T n,
+                                             const DIV& div, uint32_t j)
 {
-    if (width < 1 || n == 0) { copy_plain<G>(dst, src, n, j); return; }
-    for (uint64_t p = (uint64_t)j * 16; p < n; p += G * 16) {
-        const uint64_t last = p + 16 <= n ? p + 15 : n - 1;
-        const uint64_t l0 = p / width, l1 = last / width;
+    const uint32_t width = div.width;
+    if (width < 1 || n == 0) { copy_plain<G, T>(dst, src, n, j); return; }
+    for (T p = (T)j * 16; p < n; p += G * 16) {
+        const T last = p + 16 <= n ? p + 15 : n - 1;
+        const T l0 = (T)div(p), l1 = (T)div(last);
         if (l0 == l1 && p + 16 <= n) {
             copy16(dst + p + l0, src + p);
-        } else if (l1 == l0 + 1 && width >= 16 && (l0 + 1) * (uint64_t)width >= 16 && (l0 + 1) * (uint64_t)width + 16 <= n) {
+        } else if (l1 == l0 + 1 && width >= 16 && (l0 + 1) * (T)width >= 16 && (l0 + 1) * (T)width + 16 <= n) {
             // the chunk straddles one line break: the 16 bytes that end the line and the 16 bytes that
             // start the next one, each as one copy (what they overlap of the neighbour chunks has the
             // same values)
-            const uint64_t b = (l0 + 1) * (uint64_t)width;          // first base of the next line
+            const T b = (l0 + 1) * (T)width;          // first base of the next line
             copy16(dst + b - 16 + l0, src + b - 16);
             copy16(dst + b + l1, src + b);
         } else {
-            for (uint64_t k = p; k <= last; k++) dst[k + k / width] = src[k];
+            for (T k = p; k <= last; k++) dst[k + (T)div(k)] = src[k];
         }
     }
-    const uint64_t breaks = (n - 1) / width;
-    for (uint64_t b = 1 + j; b <= breaks; b += G) dst[b * width + b - 1] = '\n';
+    const T breaks = (T)div(n - 1);
+    for (T b = 1 + j; b <= breaks; b += G) dst[b * width + b - 1] = '\n';
+}
+
+template <typename T>
+__device__ __forceinline__ T wrapped_len_t(T len, uint32_t width, T breaks)
+{
+    return (width < 1 || len == 0) ? len : len + breaks;
+}
+
+// One record's text at o (where its first byte goes), by the G lanes of its group; lane j of the group.
+// Bases and qualities of a record longer than SKH_LONG_T are left to k_fmt_write_long.
+template <uint32_t G, typename T, typename DIV>
+__device__ __forceinline__ void write_record_text(const FormatSeqArgs& a, uint8_t* __restrict__ o, uint64_t s, T len,
+                                                  uint32_t nl, uint64_t name, const DIV& div, uint32_t j)
+{
+    if (a.print_name) {
+        if (a.print_seq) { if (j == 0) *o = (a.empty_fasta && len == 0) ? (uint8_t)'>' : a.mark; o++; }
+        copy_plain<G, uint32_t>(o, a.text + name, nl, j);
+        if (j == 0) o[nl] = '\n';
+        o += nl + 1;
+    }
+    const bool is_long = len > SKH_LONG_T;
+    const T w = wrapped_len_t<T>(len, a.width, (a.width < 1 || len == 0) ? 0 : (T)div(len - 1));
+    if (a.print_seq) {
+        if (!is_long) copy_wrapped<G, T, DIV>(o, a.seq + s, len, div, j);
+        if (j == 0) o[w] = '\n';
+        o += w + 1;
+    }
+    if (a.print_qual && !(a.empty_fasta && len == 0)) {
+        if (a.plus_line) { if (j == 0) { o[0] = '+'; o[1] = '\n'; } o += 2; }
+        if (a.qual) {
+            if (!is_long && len) copy_wrapped<G, T, DIV>(o, a.qual + s, len, div, j);
+            if (j == 0) o[w] = '\n';
+        } else if (j == 0) {
+            o[0] = '\n';                      // no quality plane: an empty quality string
+        }
+    }
+}
+
+// The output text of consecutive records is one contiguous stretch.  A wavefront takes as many records
+// per step as fit its LDS stage (from the mean record size, at most 64), puts their text together there
+// -- the pieces of a record start at any byte, which costs LDS next to nothing, while every misaligned
+// or partial store to global memory is a request of its own to the memory pipeline -- and writes the
+// stretch out as aligned 16-byte chunks in whole-wavefront rows; the bytes at either end that share a
+// chunk with the neighbouring step go byte by byte.  A step whose text does not fit the stage (long
+// records) is counted and left to k_fmt_write_direct.
+constexpr uint32_t FW_STAGE = 7 * 1024;
+
+__device__ __forceinline__ uint32_t fmt_records_per_step(uint64_t total, uint64_t nrec)
+{
+    const uint64_t mean = nrec ? total / nrec + 1 : 1;
+    const uint64_t r = (FW_STAGE - 64) * 7 / 8 / mean;
+    return r < 1 ? 1u : (r > 64 ? 64u : (uint32_t)r);
 }
 
 __global__ __launch_bounds__(FB) void k_fmt_write(const FormatSeqArgs a, const uint64_t* __restrict__ size,
                                                   const uint64_t* __restrict__ pos, const uint32_t* __restrict__ shown_name,
-                                                  const uint64_t* __restrict__ total, uint8_t* __restrict__ out,
-                                                  uint64_t out_capacity)
+                                                  const uint64_t* __restrict__ total, uint32_t* __restrict__ n_direct,
+                                                  uint8_t* __restrict__ out, uint64_t out_capacity)
+{
+    constexpr uint32_t G = 16, GROUPS = 64 / G;
+    __shared__ __attribute__((aligned(16))) uint8_t s_stage[FB / 64][FW_STAGE + 32];
+    const uint64_t tot = *total;
+    if (tot > out_capacity) return;
+    const uint32_t lane = threadIdx.x & 63, j = lane & (G - 1), grp = lane / G;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t R = fmt_records_per_step(tot, a.nrec);
+    const uint64_t nsteps = (a.nrec + R - 1) / R;
+    const Div32 div(a.width);
+    uint8_t* stage = s_stage[wave];
+    for (uint64_t step = (uint64_t)blockIdx.x * (FB / 64) + wave; step < nsteps; step += (uint64_t)gridDim.x * (FB / 64)) {
+        const uint64_t r0 = step * R;
+        const uint32_t n = a.nrec - r0 < R ? (uint32_t)(a.nrec - r0) : R;
+        // lane i holds the tables of record r0 + i
+        uint64_t t_pos = 0, t_end = 0, t_s = 0, t_name = 0;
+        uint32_t t_nl = 0, t_len = 0;
+        if (lane < n) {
+            const uint64_t r = r0 + lane;
+            const uint64_t s = a.offsets[r], e = a.offsets[r + 1];
+            t_pos = pos[r]; t_end = t_pos + size[r]; t_s = s; t_len = (uint32_t)(e - s);
+            if (a.print_name) { t_nl = shown_name[r]; t_name = a.name_pos[r]; }
+        }
+        const uint64_t p0 = from_lane64(t_pos, 0), p1 = from_lane64(t_end, n - 1);
+        const uint64_t a0 = p0 & ~15ull;
+        if (p1 - a0 > FW_STAGE) {                          // wave-uniform
+            if (lane == 0) atomicAdd(n_direct, 1u);
+            continue;
+        }
+        const uint32_t t_size = (uint32_t)(t_end - t_pos);
+        if (p1 == p0) continue;
+        for (uint32_t base = 0; base < n; base += GROUPS) {          // every lane takes part in the cross-lane reads
+            const uint32_t i = base + grp < n ? base + grp : n - 1;
+            const uint32_t sz = (uint32_t)__shfl((int)t_size, (int)i), len = (uint32_t)__shfl((int)t_len, (int)i);
+            const uint32_t nl = (uint32_t)__shfl((int)t_nl, (int)i);
+            const uint64_t p = from_lane64(t_pos, i), s = from_lane64(t_s, i), name = from_lane64(t_name, i);
+            if (base + grp < n && sz != 0)
+                write_record_text<G, uint32_t, Div32>(a, stage + (uint32_t)(p - a0), s, len, nl, name, div, j);
+        }
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t nbytes = (uint32_t)(p1 - a0), head = (uint32_t)(p0 - a0);
+        const uint32_t c_lo = head ? 16u : 0u, c_hi = nbytes & ~15u;
+        for (uint32_t c = lane * 16; c < c_hi; c += 1024)
+            if (c >= c_lo) *reinterpret_cast<uint4*>(out + a0 + c) = *reinterpret_cast<const uint4*>(stage + c);
+        if (head && lane >= head && lane < 16 && lane < nbytes) out[a0 + lane] = stage[lane];
+        if (c_hi < nbytes && (c_hi != 0 || !head) && lane < nbytes - c_hi) out[a0 + c_hi + lane] = stage[c_hi + lane];
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// The records of the steps k_fmt_write left out (their text does not fit the LDS stage), written straight
+// to global memory by 16 lanes per record.
+__global__ __launch_bounds__(FB) void k_fmt_write_direct(const FormatSeqArgs a, const uint64_t* __restrict__ size,
+                                                         const uint64_t* __restrict__ pos, const uint32_t* __restrict__ shown_name,
+                                                         const uint64_t* __restrict__ total, const uint32_t* __restrict__ n_direct,
+                                                         uint8_t* __restrict__ out, uint64_t out_capacity)
 {
     constexpr uint32_t G = 16;
-    if (*total > out_capacity) return;
+    const uint64_t tot = *total;
+    if (*n_direct == 0 || tot > out_capacity) return;
     const uint32_t j = threadIdx.x & (G - 1);
     const uint32_t leader = (threadIdx.x & 63) & ~(G - 1);
+    const uint32_t R = fmt_records_per_step(tot, a.nrec);
+    const Div64 div{a.width};
     for (uint64_t r = ((uint64_t)blockIdx.x * FB + threadIdx.x) / G; r < a.nrec; r += (uint64_t)gridDim.x * (FB / G)) {
         uint64_t m_size = 0, m_pos = 0, m_s = 0, m_e = 0, m_name = 0;
         uint32_t m_nl = 0;
         if (j == 0) {
-            m_size = size[r];
+            // the step of this record, as k_fmt_write saw it
+            const uint64_t r0 = r / R * R, rl = (a.nrec - r0 < R ? a.nrec : r0 + R) - 1;
+            const uint64_t p0 = pos[r0], p1 = pos[rl] + size[rl];
+            if (p1 - (p0 & ~15ull) > FW_STAGE) m_size = size[r];
             if (m_size != 0) {
                 m_pos = pos[r]; m_s = a.offsets[r]; m_e = a.offsets[r + 1];
                 if (a.print_name) { m_nl = shown_name[r]; m_name = a.name_pos[r]; }
             }
         }
         if (from_lane64(m_size, leader) == 0) continue;
-        uint8_t* o = out + from_lane64(m_pos, leader);
         const uint64_t s = from_lane64(m_s, leader), len = from_lane64(m_e, leader) - s;
-        if (a.print_name) {
-            const uint32_t nl = __shfl(m_nl, leader);
-            if (a.print_seq) { if (j == 0) *o = (a.empty_fasta && len == 0) ? (uint8_t)'>' : a.mark; o++; }
-            copy_plain<G>(o, a.text + from_lane64(m_name, leader), nl, j);
-            if (j == 0) o[nl] = '\n';
-            o += nl + 1;
-        }
-        const bool is_long = len > SKH_LONG_T;           // bases and qualities: k_fmt_write_long
-        if (a.print_seq) {
-            if (!is_long) copy_wrapped<G>(o, a.seq + s, len, a.width, j);
-            const uint64_t w = wrapped_len(len, a.width);
-            if (j == 0) o[w] = '\n';
-            o += w + 1;
-        }
-        if (a.print_qual && !(a.empty_fasta && len == 0)) {
-            if (a.plus_line) { if (j == 0) { o[0] = '+'; o[1] = '\n'; } o += 2; }
-            const uint64_t ql = a.qual ? len : 0;
-            if (!is_long && ql) copy_wrapped<G>(o, a.qual + s, ql, a.width, j);
-            const uint64_t w = wrapped_len(ql, a.width);
-            if (j == 0) o[w] = '\n';
-        }
+        write_record_text<G, uint64_t, Div64>(a, out + from_lane64(m_pos, leader), s, len, __shfl(m_nl, leader),
+                                              from_lane64(m_name, leader), div, j);
     }
 }
 
@@ -408,14 +517,14 @@ __global__ __launch_bounds__(FB) void k_tab_write(const FormatTabArgs a, const u
         uint8_t* o = out + from_lane64(m_pos, leader);
         const uint64_t s = from_lane64(m_s, leader), len = from_lane64(m_e, leader) - s;
         const uint32_t nl = __shfl(m_nl, leader);
-        copy_plain<G>(o, a.text + from_lane64(m_name, leader), nl, j);
+        copy_plain<G, uint32_t>(o, a.text + from_lane64(m_name, leader), nl, j);
         if (j == 0) o[nl] = '\t';
         o += nl + 1;
         const bool is_long = len > SKH_LONG_T;           // bases and qualities: k_tab_write_long
-        if (a.print_seq) { if (!is_long) copy_plain<G>(o, a.seq + s, len, j); o += len; }
+        if (a.print_seq) { if (!is_long) copy_plain<G, uint64_t>(o, a.seq + s, len, j); o += len; }
         if (j == 0) *o = '\t';
         o++;
-        if (a.print_qual) { if (!is_long) copy_plain<G>(o, a.qual + s, len, j); o += len; }
+        if (a.print_qual) { if (!is_long) copy_plain<G, uint64_t>(o, a.qual + s, len, j); o += len; }
     }
 }
 
@@ -525,8 +634,11 @@ hipError_t launch_format_seq(const FormatSeqArgs& a, uint8_t* out, uint64_t out_
     hipLaunchKernelGGL(k_scan_partials64, dim3((uint32_t)npart), dim3(FB), 0, s, size, a.nrec, part);
     hipLaunchKernelGGL(k_scan_top64, dim3(1), dim3(1024), 0, s, part, npart, total);
     hipLaunchKernelGGL(k_scan_apply64, dim3((uint32_t)npart), dim3(FB), 0, s, size, a.nrec, part, pos);
-    hipLaunchKernelGGL(k_fmt_write, dim3(capped((a.nrec * 16 + FB - 1) / FB)), dim3(FB), 0, s, a, size, pos, shown, total,
+    uint32_t* n_direct = n_long + 1;                                 // third word
+    hipLaunchKernelGGL(k_fmt_write, dim3(capped((a.nrec + 7) / 8)), dim3(FB), 0, s, a, size, pos, shown, total, n_direct,
                        out, out_capacity);
+    hipLaunchKernelGGL(k_fmt_write_direct, dim3(capped((a.nrec * 16 + FB - 1) / FB)), dim3(FB), 0, s, a, size, pos, shown, total,
+                       n_direct, out, out_capacity);
     if (a.nrec != 0 && (a.print_seq || a.print_qual))
         hipLaunchKernelGGL(k_fmt_write_long, dim3(2048), dim3(FB), 0, s, a, size, pos, shown, total, n_long, out, out_capacity);
     hipLaunchKernelGGL(k_fmt_finish, dim3(1), dim3(1), 0, s, total, out_capacity, res);
