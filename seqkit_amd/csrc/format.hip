@@ -241,6 +241,14 @@ __device__ __forceinline__ uint32_t fmt_records_per_step(uint64_t total, uint64_
     return r < 1 ? 1u : (r > 64 ? 64u : (uint32_t)r);
 }
 
+// true when the writer that puts rows together in LDS left the step of record r to the direct kernels
+__device__ __forceinline__ bool step_is_direct(uint64_t r, uint32_t R, uint64_t nrec, const uint64_t* __restrict__ pos,
+                                               const uint64_t* __restrict__ size)
+{
+    const uint64_t r0 = r / R * R, rl = (nrec - r0 < R ? nrec : r0 + R) - 1;
+    return pos[rl] + size[rl] - (pos[r0] & ~15ull) > FW_STAGE;
+}
+
 __global__ __launch_bounds__(FB) void k_fmt_write(const FormatSeqArgs a, const uint64_t* __restrict__ size,
                                                   const uint64_t* __restrict__ pos, const uint32_t* __restrict__ shown_name,
                                                   const uint64_t* __restrict__ total, uint32_t* __restrict__ n_direct,
@@ -313,10 +321,7 @@ __global__ __launch_bounds__(FB) void k_fmt_write_direct(const FormatSeqArgs a, 
         uint64_t m_size = 0, m_pos = 0, m_s = 0, m_e = 0, m_name = 0;
         uint32_t m_nl = 0;
         if (j == 0) {
-            // the step of this record, as k_fmt_write saw it
-            const uint64_t r0 = r / R * R, rl = (a.nrec - r0 < R ? a.nrec : r0 + R) - 1;
-            const uint64_t p0 = pos[r0], p1 = pos[rl] + size[rl];
-            if (p1 - (p0 & ~15ull) > FW_STAGE) m_size = size[r];
+            if (step_is_direct(r, R, a.nrec, pos, size)) m_size = size[r];
             if (m_size != 0) {
                 m_pos = pos[r]; m_s = a.offsets[r]; m_e = a.offsets[r + 1];
                 if (a.print_name) { m_nl = shown_name[r]; m_name = a.name_pos[r]; }
@@ -394,19 +399,42 @@ __global__ __launch_bounds__(FB) void k_fmt_write_long(const FormatSeqArgs a, co
 
 // ---- fx2tab rows ------------------------------------------------------------------------------
 
+// number of decimal digits of v, and v in decimal at buf[0 .. nd) (32-bit arithmetic whenever v fits)
+__device__ __forceinline__ uint32_t ndigits(uint64_t v)
+{
+    uint32_t n = 1;
+    if (v >> 32) {
+        while (v >= 10) { v /= 10; n++; }
+        return n;
+    }
+    uint32_t x = (uint32_t)v;
+    while (x >= 10) { x /= 10; n++; }
+    return n;
+}
+
+__device__ __forceinline__ void put_decimal(uint64_t v, uint32_t nd, uint8_t* buf)
+{
+    if (v >> 32) {
+        for (uint32_t k = nd; k-- > 0;) { buf[k] = (uint8_t)('0' + v % 10); v /= 10; }
+        return;
+    }
+    uint32_t x = (uint32_t)v;
+    for (uint32_t k = nd; k-- > 0;) { buf[k] = (uint8_t)('0' + x % 10); x /= 10; }
+}
+
 // "%.2f" of v, exactly as C and Go print it: the binary value is rounded to hundredths with
 // ties to even on the exact value (integer arithmetic; |v| < 2^52 here: percentages).
-// Returns the number of characters written to buf (at most 24).
-__device__ __forceinline__ uint32_t fmt_fixed2(double v, char* buf)
+struct Fixed2 { uint64_t ip; uint32_t fp; uint32_t kind; bool neg; };     // kind: 0 = number, 1 = NaN, 2 = infinity
+
+__device__ __forceinline__ Fixed2 fixed2_of(double v)
 {
     const uint64_t bits = (uint64_t)__double_as_longlong(v);
-    const bool neg = (bits >> 63) != 0;
+    Fixed2 f;
+    f.neg = (bits >> 63) != 0;
+    f.ip = 0; f.fp = 0; f.kind = 0;
     const uint32_t E = (uint32_t)((bits >> 52) & 0x7ff);
     const uint64_t frac = bits & ((1ull << 52) - 1);
-    if (E == 0x7ff) {
-        if (frac) { buf[0] = 'N'; buf[1] = 'a'; buf[2] = 'N'; return 3; }
-        buf[0] = neg ? '-' : '+'; buf[1] = 'I'; buf[2] = 'n'; buf[3] = 'f'; return 4;
-    }
+    if (E == 0x7ff) { f.kind = frac ? 1u : 2u; return f; }
     // |v| = m * 2^-sh
     const uint64_t m = E ? (frac | (1ull << 52)) : frac;
     const int sh = E ? 1075 - (int)E : 1074;
@@ -418,30 +446,28 @@ __device__ __forceinline__ uint32_t fmt_fixed2(double v, char* buf)
         const uint64_t rem = P & ((1ull << sh) - 1), half = 1ull << (sh - 1);
         if (rem > half || (rem == half && (q & 1))) q++;
     }
-    uint32_t n = 0;
-    if (neg) buf[n++] = '-';
-    uint64_t ip = q / 100;
-    const uint32_t fp = (uint32_t)(q % 100);
-    char tmp[20];
-    uint32_t k = 0;
-    do { tmp[k++] = (char)('0' + ip % 10); ip /= 10; } while (ip);
-    while (k) buf[n++] = tmp[--k];
-    buf[n++] = '.';
-    buf[n++] = (char)('0' + fp / 10);
-    buf[n++] = (char)('0' + fp % 10);
-    return n;
+    if (q >> 32) { f.ip = q / 100; f.fp = (uint32_t)(q % 100); }
+    else { const uint32_t q32 = (uint32_t)q; f.ip = q32 / 100; f.fp = q32 % 100; }
+    return f;
 }
 
-__device__ __forceinline__ uint32_t fmt_u64(uint64_t v, char* buf)
+// characters of the text of f; with PUT also written to buf (at most 24)
+template <bool PUT>
+__device__ __forceinline__ uint32_t fixed2_text(const Fixed2& f, uint8_t* buf)
 {
-    char tmp[20];
-    uint32_t k = 0, n = 0;
-    do { tmp[k++] = (char)('0' + v % 10); v /= 10; } while (v);
-    while (k) buf[n++] = tmp[--k];
-    return n;
+    if (f.kind == 1) { if (PUT) { buf[0] = 'N'; buf[1] = 'a'; buf[2] = 'N'; } return 3; }
+    if (f.kind == 2) { if (PUT) { buf[0] = f.neg ? '-' : '+'; buf[1] = 'I'; buf[2] = 'n'; buf[3] = 'f'; } return 4; }
+    uint32_t n = 0;
+    if (f.neg) { if (PUT) buf[0] = '-'; n = 1; }
+    const uint32_t nd = ndigits(f.ip);
+    if (PUT) {
+        put_decimal(f.ip, nd, buf + n);
+        buf[n + nd] = '.';
+        buf[n + nd + 1] = (uint8_t)('0' + f.fp / 10);
+        buf[n + nd + 2] = (uint8_t)('0' + f.fp % 10);
+    }
+    return n + nd + 3;
 }
-
-constexpr uint32_t TAB_NUM_MAX = 26 * TAB_MAX_COLS;     // characters of all numeric columns of a row
 
 __device__ __forceinline__ uint64_t tab_term_sum(const FormatTabArgs& a, const TabColumn& c, uint64_t r)
 {
@@ -453,19 +479,27 @@ __device__ __forceinline__ uint64_t tab_term_sum(const FormatTabArgs& a, const T
     return sum;
 }
 
-// the numeric columns of record r ("\t<number>" each), as fx2tab.go:127-143 prints them
-__device__ uint32_t tab_numbers(const FormatTabArgs& a, uint64_t r, uint64_t len, char* buf)
+// The numeric columns of record r ("\t<number>" each), as fx2tab.go:127-143 prints them: their length,
+// and with PUT their characters at buf.
+template <bool PUT>
+__device__ uint32_t tab_numbers(const FormatTabArgs& a, uint64_t r, uint64_t len, uint8_t* buf)
 {
     uint32_t n = 0;
     double gg = 0, cc = 0;
     bool have_gc = false;
     for (uint32_t ci = 0; ci < a.ncols; ci++) {
         const TabColumn& c = a.cols[ci];
-        buf[n++] = '\t';
-        if (c.kind == TAB_LENGTH) { n += fmt_u64(len, buf + n); continue; }
+        if (PUT) buf[n] = '\t';
+        n++;
+        if (c.kind == TAB_LENGTH) {
+            const uint32_t nd = ndigits(len);
+            if (PUT) put_decimal(len, nd, buf + n);
+            n += nd;
+            continue;
+        }
         if (c.kind == TAB_CONTENT) {
             const double v = len ? (double)tab_term_sum(a, c, r) / (double)len : 0.0;
-            n += fmt_fixed2(v * 100, buf + n);
+            n += fixed2_text<PUT>(fixed2_of(v * 100), buf + n);
             continue;
         }
         if (!have_gc) {
@@ -475,10 +509,29 @@ __device__ uint32_t tab_numbers(const FormatTabArgs& a, uint64_t r, uint64_t len
             cc = len ? (double)a.counts[pc][r * a.nclass[pc] + kc] / (double)len : 0.0;
             have_gc = true;
         }
-        if (c.kind == TAB_GC) n += fmt_fixed2((gg + cc) * 100, buf + n);
-        else n += fmt_fixed2((gg - cc) / (gg + cc) * 100, buf + n);
+        if (c.kind == TAB_GC) n += fixed2_text<PUT>(fixed2_of((gg + cc) * 100), buf + n);
+        else n += fixed2_text<PUT>(fixed2_of((gg - cc) / (gg + cc) * 100), buf + n);
     }
     return n;
+}
+
+// what follows the quality field of row r: the numeric columns, the alphabet column (fx2tab.go:145-147:
+// a tab and the byte values present, ascending) and the line end
+__device__ __forceinline__ void tab_row_tail(const FormatTabArgs& a, uint64_t r, uint64_t len, uint8_t* o)
+{
+    o += tab_numbers<true>(a, r, len, o);
+    if (a.letters) {
+        *o++ = '\t';
+        for (uint32_t i = 0; i < 8; i++) {
+            uint32_t w = a.letters[r * 8 + i];
+            while (w) {
+                const uint32_t bit = (uint32_t)__builtin_ctz(w);
+                *o++ = (uint8_t)(32 * i + bit);
+                w &= w - 1;
+            }
+        }
+    }
+    *o = '\n';
 }
 
 __global__ __launch_bounds__(FB) void k_tab_sizes(const FormatTabArgs a, uint64_t* __restrict__ size,
@@ -488,8 +541,7 @@ __global__ __launch_bounds__(FB) void k_tab_sizes(const FormatTabArgs a, uint64_
         const uint64_t len = a.offsets[r + 1] - a.offsets[r];
         uint32_t nl = a.name_len[r];
         if (a.only_id) nl = id_length(a.text + a.name_pos[r], nl);
-        char buf[TAB_NUM_MAX];
-        const uint32_t nn = tab_numbers(a, r, len, buf);
+        const uint32_t nn = tab_numbers<false>(a, r, len, nullptr);
         uint32_t na = 0;                                  // alphabet column: a tab and the letters present
         if (a.letters) {
             na = 1;
@@ -501,19 +553,92 @@ __global__ __launch_bounds__(FB) void k_tab_sizes(const FormatTabArgs a, uint64_
     }
 }
 
-__global__ __launch_bounds__(FB) void k_tab_write(const FormatTabArgs a, const uint64_t* __restrict__ pos,
+// Rows of as many records as fit the LDS stage, put together there by one wavefront and written out as
+// aligned whole-wavefront rows (see k_fmt_write).  The numeric columns are formatted by one lane per
+// record, all lanes busy; names, bases and qualities are copied by 16 lanes per record.
+__global__ __launch_bounds__(FB) void k_tab_rows(const FormatTabArgs a, const uint64_t* __restrict__ size,
+                                                 const uint64_t* __restrict__ pos, const uint32_t* __restrict__ shown_name,
+                                                 const uint64_t* __restrict__ total, uint32_t* __restrict__ n_direct,
+                                                 uint8_t* __restrict__ out, uint64_t out_capacity)
+{
+    constexpr uint32_t G = 16, GROUPS = 64 / G;
+    __shared__ __attribute__((aligned(16))) uint8_t s_stage[FB / 64][FW_STAGE + 32];
+    const uint64_t tot = *total;
+    if (tot > out_capacity) return;
+    const uint32_t lane = threadIdx.x & 63, j = lane & (G - 1), grp = lane / G;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t R = fmt_records_per_step(tot, a.nrec);
+    const uint64_t nsteps = (a.nrec + R - 1) / R;
+    uint8_t* stage = s_stage[wave];
+    for (uint64_t step = (uint64_t)blockIdx.x * (FB / 64) + wave; step < nsteps; step += (uint64_t)gridDim.x * (FB / 64)) {
+        const uint64_t r0 = step * R;
+        const uint32_t n = a.nrec - r0 < R ? (uint32_t)(a.nrec - r0) : R;
+        // lane i holds the tables of record r0 + i
+        uint64_t t_pos = 0, t_end = 0, t_s = 0, t_name = 0;
+        uint32_t t_nl = 0, t_len = 0;
+        if (lane < n) {
+            const uint64_t r = r0 + lane;
+            const uint64_t s = a.offsets[r], e = a.offsets[r + 1];
+            t_pos = pos[r]; t_end = t_pos + size[r]; t_s = s; t_len = (uint32_t)(e - s);
+            t_nl = shown_name[r]; t_name = a.name_pos[r];
+        }
+        const uint64_t p0 = from_lane64(t_pos, 0), p1 = from_lane64(t_end, n - 1);
+        const uint64_t a0 = p0 & ~15ull;
+        if (p1 - a0 > FW_STAGE) {                          // wave-uniform
+            if (lane == 0) atomicAdd(n_direct, 1u);
+            continue;
+        }
+        // (a row that fits the stage holds its bases and qualities: the record is shorter than the stage)
+        if (lane < n) {
+            const uint32_t at = (uint32_t)(t_pos - a0) + t_nl + 1 + (a.print_seq ? t_len : 0) + 1 + (a.print_qual ? t_len : 0);
+            tab_row_tail(a, r0 + lane, t_len, stage + at);
+        }
+        for (uint32_t base = 0; base < n; base += GROUPS) {          // every lane takes part in the cross-lane reads
+            const uint32_t i = base + grp < n ? base + grp : n - 1;
+            const uint32_t len = (uint32_t)__shfl((int)t_len, (int)i), nl = (uint32_t)__shfl((int)t_nl, (int)i);
+            const uint64_t p = from_lane64(t_pos, i), s = from_lane64(t_s, i), name = from_lane64(t_name, i);
+            if (base + grp < n) {
+                uint8_t* o = stage + (uint32_t)(p - a0);
+                copy_plain<G, uint32_t>(o, a.text + name, nl, j);
+                if (j == 0) o[nl] = '\t';
+                o += nl + 1;
+                if (a.print_seq) { copy_plain<G, uint32_t>(o, a.seq + s, len, j); o += len; }
+                if (j == 0) *o = '\t';
+                o++;
+                if (a.print_qual) copy_plain<G, uint32_t>(o, a.qual + s, len, j);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t nbytes = (uint32_t)(p1 - a0), head = (uint32_t)(p0 - a0);
+        const uint32_t c_lo = head ? 16u : 0u, c_hi = nbytes & ~15u;
+        for (uint32_t c = lane * 16; c < c_hi; c += 1024)
+            if (c >= c_lo) *reinterpret_cast<uint4*>(out + a0 + c) = *reinterpret_cast<const uint4*>(stage + c);
+        if (head && lane >= head && lane < 16 && lane < nbytes) out[a0 + lane] = stage[lane];
+        if (c_hi < nbytes && (c_hi != 0 || !head) && lane < nbytes - c_hi) out[a0 + c_hi + lane] = stage[c_hi + lane];
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// The rows of the steps k_tab_rows left out, straight to global memory: names, bases and qualities ...
+__global__ __launch_bounds__(FB) void k_tab_write(const FormatTabArgs a, const uint64_t* __restrict__ size,
+                                                  const uint64_t* __restrict__ pos,
                                                   const uint32_t* __restrict__ shown_name,
-                                                  const uint64_t* __restrict__ total, uint8_t* __restrict__ out,
-                                                  uint64_t out_capacity)
+                                                  const uint64_t* __restrict__ total, const uint32_t* __restrict__ n_direct,
+                                                  uint8_t* __restrict__ out, uint64_t out_capacity)
 {
     constexpr uint32_t G = 16;
-    if (*total > out_capacity) return;
+    const uint64_t tot = *total;
+    if (*n_direct == 0 || tot > out_capacity) return;
     const uint32_t j = threadIdx.x & (G - 1);
     const uint32_t leader = (threadIdx.x & 63) & ~(G - 1);
+    const uint32_t R = fmt_records_per_step(tot, a.nrec);
     for (uint64_t r = ((uint64_t)blockIdx.x * FB + threadIdx.x) / G; r < a.nrec; r += (uint64_t)gridDim.x * (FB / G)) {
         uint64_t m_pos = 0, m_s = 0, m_e = 0, m_name = 0;
-        uint32_t m_nl = 0;
-        if (j == 0) { m_pos = pos[r]; m_s = a.offsets[r]; m_e = a.offsets[r + 1]; m_nl = shown_name[r]; m_name = a.name_pos[r]; }
+        uint32_t m_nl = 0, m_take = 0;
+        if (j == 0 && step_is_direct(r, R, a.nrec, pos, size)) {
+            m_take = 1; m_pos = pos[r]; m_s = a.offsets[r]; m_e = a.offsets[r + 1]; m_nl = shown_name[r]; m_name = a.name_pos[r];
+        }
+        if (__shfl(m_take, leader) == 0) continue;
         uint8_t* o = out + from_lane64(m_pos, leader);
         const uint64_t s = from_lane64(m_s, leader), len = from_lane64(m_e, leader) - s;
         const uint32_t nl = __shfl(m_nl, leader);
@@ -525,6 +650,23 @@ __global__ __launch_bounds__(FB) void k_tab_write(const FormatTabArgs a, const u
         if (j == 0) *o = '\t';
         o++;
         if (a.print_qual) { if (!is_long) copy_plain<G, uint64_t>(o, a.qual + s, len, j); o += len; }
+    }
+}
+
+// ... and the numeric columns and the line end, one thread per record
+__global__ __launch_bounds__(FB) void k_tab_numbers(const FormatTabArgs a, const uint64_t* __restrict__ size,
+                                                    const uint64_t* __restrict__ pos,
+                                                    const uint32_t* __restrict__ shown_name,
+                                                    const uint64_t* __restrict__ total, const uint32_t* __restrict__ n_direct,
+                                                    uint8_t* __restrict__ out, uint64_t out_capacity)
+{
+    const uint64_t tot = *total;
+    if (*n_direct == 0 || tot > out_capacity) return;
+    const uint32_t R = fmt_records_per_step(tot, a.nrec);
+    for (uint64_t r = (uint64_t)blockIdx.x * FB + threadIdx.x; r < a.nrec; r += (uint64_t)gridDim.x * FB) {
+        if (!step_is_direct(r, R, a.nrec, pos, size)) continue;
+        const uint64_t len = a.offsets[r + 1] - a.offsets[r];
+        tab_row_tail(a, r, len, out + pos[r] + shown_name[r] + 1 + (a.print_seq ? len : 0) + 1 + (a.print_qual ? len : 0));
     }
 }
 
@@ -555,36 +697,6 @@ __global__ __launch_bounds__(FB) void k_tab_write_long(const FormatTabArgs a, co
             o++;
             if (a.print_qual) copy_wrapped_range(o, a.qual + s, len, 0, k0, k1);
         }
-    }
-}
-
-// the numeric columns and the line end of every row: one thread per record (all lanes busy;
-// done by one lane of a record's group the byte stores take ten times as long)
-__global__ __launch_bounds__(FB) void k_tab_numbers(const FormatTabArgs a, const uint64_t* __restrict__ pos,
-                                                    const uint32_t* __restrict__ shown_name,
-                                                    const uint64_t* __restrict__ total, uint8_t* __restrict__ out,
-                                                    uint64_t out_capacity)
-{
-    if (*total > out_capacity) return;
-    for (uint64_t r = (uint64_t)blockIdx.x * FB + threadIdx.x; r < a.nrec; r += (uint64_t)gridDim.x * FB) {
-        const uint64_t len = a.offsets[r + 1] - a.offsets[r];
-        uint8_t* o = out + pos[r] + shown_name[r] + 1 + (a.print_seq ? len : 0) + 1 + (a.print_qual ? len : 0);
-        char buf[TAB_NUM_MAX];
-        const uint32_t nn = tab_numbers(a, r, len, buf);
-        for (uint32_t k = 0; k < nn; k++) o[k] = (uint8_t)buf[k];
-        o += nn;
-        if (a.letters) {                                  // fx2tab.go:145-147: the byte values present, ascending
-            *o++ = '\t';
-            for (uint32_t i = 0; i < 8; i++) {
-                uint32_t w = a.letters[r * 8 + i];
-                while (w) {
-                    const uint32_t bit = (uint32_t)__builtin_ctz(w);
-                    *o++ = (uint8_t)(32 * i + bit);
-                    w &= w - 1;
-                }
-            }
-        }
-        *o = '\n';
     }
 }
 
@@ -656,16 +768,21 @@ hipError_t launch_format_tab(const FormatTabArgs& a, uint8_t* out, uint64_t out_
     uint64_t* part = reinterpret_cast<uint64_t*>(ws);
     const uint64_t npart = (a.nrec + FSCAN_TILE - 1) / FSCAN_TILE ? (a.nrec + FSCAN_TILE - 1) / FSCAN_TILE : 1;
     auto capped = [](uint64_t b) { return (uint32_t)(b < 1 ? 1 : (b > 16384 ? 16384 : b)); };
+    hipError_t e = hipMemsetAsync(total, 0, 16, s);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_tab_sizes, dim3(capped((a.nrec + FB - 1) / FB)), dim3(FB), 0, s, a, size, shown);
     hipLaunchKernelGGL(k_scan_partials64, dim3((uint32_t)npart), dim3(FB), 0, s, size, a.nrec, part);
     hipLaunchKernelGGL(k_scan_top64, dim3(1), dim3(1024), 0, s, part, npart, total);
     hipLaunchKernelGGL(k_scan_apply64, dim3((uint32_t)npart), dim3(FB), 0, s, size, a.nrec, part, pos);
-    hipLaunchKernelGGL(k_tab_write, dim3(capped((a.nrec * 16 + FB - 1) / FB)), dim3(FB), 0, s, a, pos, shown, total, out,
+    uint32_t* n_direct = reinterpret_cast<uint32_t*>(total + 1) + 1;     // third word of the workspace head (zeroed above)
+    hipLaunchKernelGGL(k_tab_rows, dim3(capped((a.nrec + 7) / 8)), dim3(FB), 0, s, a, size, pos, shown, total, n_direct, out,
                        out_capacity);
+    hipLaunchKernelGGL(k_tab_write, dim3(capped((a.nrec * 16 + FB - 1) / FB)), dim3(FB), 0, s, a, size, pos, shown, total,
+                       n_direct, out, out_capacity);
     if (a.nrec != 0 && (a.print_seq || a.print_qual))
         hipLaunchKernelGGL(k_tab_write_long, dim3(2048), dim3(FB), 0, s, a, pos, shown, total, out, out_capacity);
-    hipLaunchKernelGGL(k_tab_numbers, dim3(capped((a.nrec + FB - 1) / FB)), dim3(FB), 0, s, a, pos, shown, total, out,
-                       out_capacity);
+    hipLaunchKernelGGL(k_tab_numbers, dim3(capped((a.nrec + FB - 1) / FB)), dim3(FB), 0, s, a, size, pos, shown, total, n_direct,
+                       out, out_capacity);
     hipLaunchKernelGGL(k_fmt_finish, dim3(1), dim3(1), 0, s, total, out_capacity, res);
     return hipGetLastError();
 }
