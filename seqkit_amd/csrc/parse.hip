@@ -466,8 +466,41 @@ __global__ __launch_bounds__(PB) void k_parse_emit(ParseState* st, uint64_t max_
     }
 }
 
-// Copies every sequence (and quality) line of an accepted record to its place in the planes:
-// 8 lanes per line, 16 bytes per lane and pass.
+__device__ __forceinline__ uint64_t shfl64(uint64_t v, uint32_t src_lane)
+{
+    return ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(v >> 32), (int)src_lane) << 32) |
+           (uint32_t)__shfl((int)(uint32_t)v, (int)src_lane);
+}
+
+// One line's bytes, by the G lanes of its group (lane j): 16-byte pieces at any alignment, the end of the
+// line as its last 16 bytes copied once more (same values, no byte loop).
+template <uint32_t G>
+__device__ __forceinline__ void copy_line(uint8_t* __restrict__ out, const uint8_t* __restrict__ src, uint32_t len, uint32_t j)
+{
+    for (uint32_t p = j * 16; p < len; p += G * 16) {
+        uint4 v;
+        if (p + 16 <= len) {
+            __builtin_memcpy(&v, src + p, 16);
+            __builtin_memcpy(out + p, &v, 16);
+        } else if (len >= 16) {
+            __builtin_memcpy(&v, src + len - 16, 16);
+            __builtin_memcpy(out + len - 16, &v, 16);
+        } else {
+            for (uint32_t k = p; k < len; k++) out[k] = src[k];
+        }
+    }
+}
+
+// Sequence (and quality) lines to their places in the planes.  The lines a wavefront takes in one step
+// are consecutive, so what they write is one contiguous run of each plane: as many lines as fit a stage
+// of PC_STAGE bytes per plane are put together in LDS (8 lanes per line; a line lands at any byte there at
+// no cost) and leave as aligned 16-byte chunks in whole-wavefront rows, the bytes that share a chunk with
+// the neighbouring step byte by byte.  FASTQ: only the second and fourth line of a record are copied, so
+// the work items are those (two per record); FASTA: all lines (head lines contribute nothing).  A step
+// whose run does not fit the stage is copied straight to global memory; lines beyond LONG_LINE are left
+// to k_parse_copy_long.
+constexpr uint32_t PC_STAGE = 3584;
+
 template <bool FASTQ>
 __global__ __launch_bounds__(PB) void k_parse_copy(const ParseState* st, uint64_t max_records, uint64_t seq_capacity,
                                                    const uint8_t* __restrict__ text,
@@ -478,45 +511,74 @@ __global__ __launch_bounds__(PB) void k_parse_copy(const ParseState* st, uint64_
                                                    const uint32_t* __restrict__ line_rank,
                                                    uint8_t* __restrict__ seq, uint8_t* __restrict__ qual)
 {
-    constexpr uint32_t G = 8;
-    const uint32_t j = threadIdx.x & (G - 1);
-    const uint64_t nrec = st->nrec, nlines = st->nlines;
-    if (st->status != PARSE_OK || nrec > max_records || st->seq_bytes > seq_capacity) return;
-    // FASTQ: only the second and fourth line of a record are copied, so the lane groups are dealt
-    // out over those (two per record); FASTA: over all lines
+    constexpr uint32_t G = 8, GROUPS = 64 / G, NPLANE = FASTQ ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) uint8_t s_stage[PB / 64][NPLANE][PC_STAGE + 32];
+    const uint32_t lane = threadIdx.x & 63, j = lane & (G - 1), grp = lane / G;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint64_t nrec = st->nrec, nlines = st->nlines, seq_bytes = st->seq_bytes;
+    if (st->status != PARSE_OK || nrec > max_records || seq_bytes > seq_capacity) return;
     const uint64_t nwork = FASTQ ? 2 * ((nlines + 3) / 4) : nlines;
-    for (uint64_t w = ((uint64_t)blockIdx.x * PB + threadIdx.x) / G; w < nwork; w += (uint64_t)gridDim.x * (PB / G)) {
-        const uint64_t i = FASTQ ? 4 * (w >> 1) + 1 + 2 * (w & 1) : w;
-        if (i >= nlines) continue;
-        uint8_t* dst_plane;
-        uint64_t dst;
-        if (FASTQ) {
-            const uint32_t role = (uint32_t)(i & 3);
-            if ((i >> 2) >= nrec) continue;
-            dst_plane = role == 1 ? seq : qual;
-            dst = line_dst[role == 1 ? i : i - 2];
-        } else {
-            const uint32_t rank = line_rank[i];
-            if (line_head[i] || rank == 0 || rank - 1 >= nrec) continue;
-            dst_plane = seq;
-            dst = line_dst[i];
-        }
-        const uint32_t len = line_len[i];
-        if (len > LONG_LINE) continue;                   // k_parse_copy_long
-        const uint8_t* src = text + line_start[i];
-        uint8_t* out = dst_plane + dst;
-        for (uint32_t p = j * 16; p < len; p += G * 16) {
-            uint4 v;
-            if (p + 16 <= len) {
-                __builtin_memcpy(&v, src + p, 16);
-                __builtin_memcpy(out + p, &v, 16);
-            } else if (len >= 16) {                      // the last 16 bytes again: same values, no byte loop
-                __builtin_memcpy(&v, src + len - 16, 16);
-                __builtin_memcpy(out + len - 16, &v, 16);
-            } else {
-                for (uint32_t k = p; k < len; k++) out[k] = src[k];
+    // work items per step, from the mean number of bytes an item brings
+    uint32_t W;
+    {
+        const uint64_t units = FASTQ ? nrec : nlines;
+        const uint64_t mean = units ? seq_bytes / units + 1 : 1;
+        uint64_t k = PC_STAGE * 7 / 8 / mean;
+        const uint64_t kmax = FASTQ ? 32 : 64;
+        k = k < 1 ? 1 : (k > kmax ? kmax : k);
+        W = (uint32_t)(FASTQ ? 2 * k : k);
+    }
+    const uint64_t nsteps = (nwork + W - 1) / W;
+    for (uint64_t step = (uint64_t)blockIdx.x * (PB / 64) + wave; step < nsteps; step += (uint64_t)gridDim.x * (PB / 64)) {
+        // lane i holds the tables of work item step * W + i
+        const uint64_t w = step * W + lane;
+        uint64_t t_dst = 0, t_start = 0;
+        uint32_t t_len = 0, t_q = 0;
+        bool valid = false;
+        if (lane < W && w < nwork) {
+            const uint64_t i = FASTQ ? 4 * (w >> 1) + 1 + 2 * (w & 1) : w;
+            if (i < nlines) {
+                if (FASTQ) {
+                    const uint32_t role = (uint32_t)(i & 3);
+                    if ((i >> 2) < nrec) { valid = true; t_dst = line_dst[role == 1 ? i : i - 2]; t_q = role == 3; }
+                } else {
+                    const uint32_t rank = line_rank[i];
+                    if (!(line_head[i] || rank == 0 || rank - 1 >= nrec)) { valid = true; t_dst = line_dst[i]; }
+                }
+                if (valid) { t_len = line_len[i]; t_start = line_start[i]; }
             }
         }
+        const unsigned long long m = __ballot(valid);
+        if (m == 0) continue;
+        const uint32_t first = (uint32_t)__builtin_ctzll(m), last = 63u - (uint32_t)__builtin_clzll(m);
+        const uint64_t t_end = t_dst + t_len;
+        const uint64_t p0 = shfl64(t_dst, first);
+        uint64_t p1 = shfl64(t_end, last);
+        if (FASTQ && last > 0) { const uint64_t e2 = shfl64(t_end, last - 1); p1 = e2 > p1 ? e2 : p1; }
+        const uint64_t a0 = p0 & ~15ull;
+        const bool staged = !__any(valid && t_len > LONG_LINE) && p1 - a0 <= PC_STAGE;
+        for (uint32_t base = 0; base <= last; base += GROUPS) {       // every lane takes part in the cross-lane reads
+            const uint32_t i = base + grp;
+            const uint32_t len = (uint32_t)__shfl((int)t_len, (int)i), q = (uint32_t)__shfl((int)t_q, (int)i);
+            const uint64_t dst = shfl64(t_dst, i), start = shfl64(t_start, i);
+            if (len == 0 || len > LONG_LINE) continue;                 // (an item that is not valid has len 0)
+            if (staged) copy_line<G>(s_stage[wave][FASTQ ? q : 0] + (uint32_t)(dst - a0), text + start, len, j);
+            else copy_line<G>((FASTQ && q ? qual : seq) + dst, text + start, len, j);
+        }
+        if (!staged) continue;
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t nbytes = (uint32_t)(p1 - a0), head = (uint32_t)(p0 - a0);
+        const uint32_t c_lo = head ? 16u : 0u, c_hi = nbytes & ~15u;
+#pragma unroll
+        for (uint32_t pl = 0; pl < NPLANE; pl++) {
+            uint8_t* out = pl ? qual : seq;
+            const uint8_t* stage = s_stage[wave][pl];
+            for (uint32_t c = lane * 16; c < c_hi; c += 1024)
+                if (c >= c_lo) *reinterpret_cast<uint4*>(out + a0 + c) = *reinterpret_cast<const uint4*>(stage + c);
+            if (head && lane >= head && lane < 16 && lane < nbytes) out[a0 + lane] = stage[lane];
+            if (c_hi < nbytes && (c_hi != 0 || !head) && lane < nbytes - c_hi) out[a0 + c_hi + lane] = stage[c_hi + lane];
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
