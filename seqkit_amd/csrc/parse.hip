@@ -110,25 +110,45 @@ __global__ __launch_bounds__(PB) void k_nl_count(const uint8_t* __restrict__ tex
     if (threadIdx.x == 0) tile_count[blockIdx.x] = total;
 }
 
-// exclusive scan of ntile uint32 counts into uint64 bases by ONE workgroup; total -> *n_out
+// exclusive scan of ntile uint32 counts into uint64 bases by ONE workgroup; total -> *n_out.
+// 4096 counts per round: every thread takes four consecutive ones (the loads of a wavefront are one
+// contiguous kilobyte), wavefront scans by cross-lane reads, the 16 wavefront totals through LDS.
 __global__ __launch_bounds__(1024) void k_scan_tiles(const uint32_t* __restrict__ cnt, uint64_t ntile,
                                                      uint64_t* __restrict__ base, uint64_t* __restrict__ n_out)
 {
-    __shared__ uint64_t s_part[1024];
-    const uint64_t per = (ntile + 1023) / 1024;
-    const uint64_t a = threadIdx.x * per, b = a + per < ntile ? a + per : ntile;
-    uint64_t s = 0;
-    for (uint64_t i = a; i < b; i++) s += cnt[i];
-    s_part[threadIdx.x] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint64_t run = 0;
-        for (int i = 0; i < 1024; i++) { const uint64_t t = s_part[i]; s_part[i] = run; run += t; }
-        *n_out = run;
+    __shared__ uint64_t s_wave[16];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint64_t carry = 0;
+    for (uint64_t i0 = 0; i0 < ntile; i0 += 4096) {
+        const uint64_t i = i0 + 4ull * threadIdx.x;
+        uint32_t c[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) c[k] = i + k < ntile ? cnt[i + k] : 0u;
+        const uint32_t mine = c[0] + c[1] + c[2] + c[3];             // < 2^32: a tile holds at most TILE newlines
+        uint64_t inc = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint64_t t = ((uint64_t)(uint32_t)__shfl_up((int)(uint32_t)(inc >> 32), d) << 32) | (uint32_t)__shfl_up((int)(uint32_t)inc, d);
+            if ((int)lane >= d) inc += t;
+        }
+        if (lane == 63) s_wave[wave] = inc;
+        __syncthreads();
+        uint64_t before = carry, all = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < 16; w++) {
+            if (w < wave) before += s_wave[w];
+            all += s_wave[w];
+        }
+        __syncthreads();
+        uint64_t run = before + inc - mine;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (i + k < ntile) base[i + k] = run;
+            run += c[k];
+        }
+        carry += all;
     }
-    __syncthreads();
-    uint64_t run = s_part[threadIdx.x];
-    for (uint64_t i = a; i < b; i++) { base[i] = run; run += cnt[i]; }
+    if (threadIdx.x == 0) *n_out = carry;
 }
 
 __global__ __launch_bounds__(PB) void k_nl_scatter(const uint8_t* __restrict__ text, uint64_t n,
