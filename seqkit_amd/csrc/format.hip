@@ -273,7 +273,8 @@ __global__ __launch_bounds__(FB) void k_fmt_write(const FormatSeqArgs a, const u
         if (lane < n) {
             const uint64_t r = r0 + lane;
             const uint64_t s = a.offsets[r], e = a.offsets[r + 1];
-            t_pos = pos[r]; t_end = t_pos + size[r]; t_s = s; t_len = (uint32_t)(e - s);
+            t_pos = pos[r]; t_end = t_pos + size[r]; t_s = s;
+            t_len = e - s > 0xffffffffull ? 0xffffffffu : (uint32_t)(e - s);      // only its bytes that are printed count here
             if (a.print_name) { t_nl = shown_name[r]; t_name = a.name_pos[r]; }
         }
         const uint64_t p0 = from_lane64(t_pos, 0), p1 = from_lane64(t_end, n - 1);
@@ -574,12 +575,12 @@ __global__ __launch_bounds__(FB) void k_tab_rows(const FormatTabArgs a, const ui
         const uint64_t r0 = step * R;
         const uint32_t n = a.nrec - r0 < R ? (uint32_t)(a.nrec - r0) : R;
         // lane i holds the tables of record r0 + i
-        uint64_t t_pos = 0, t_end = 0, t_s = 0, t_name = 0;
-        uint32_t t_nl = 0, t_len = 0;
+        uint64_t t_pos = 0, t_end = 0, t_s = 0, t_name = 0, t_len64 = 0;
+        uint32_t t_nl = 0, t_len = 0;                     // t_len: for the copies (a printed field fits the stage)
         if (lane < n) {
             const uint64_t r = r0 + lane;
             const uint64_t s = a.offsets[r], e = a.offsets[r + 1];
-            t_pos = pos[r]; t_end = t_pos + size[r]; t_s = s; t_len = (uint32_t)(e - s);
+            t_pos = pos[r]; t_end = t_pos + size[r]; t_s = s; t_len64 = e - s; t_len = t_len64 > 0xffffffffull ? 0xffffffffu : (uint32_t)t_len64;
             t_nl = shown_name[r]; t_name = a.name_pos[r];
         }
         const uint64_t p0 = from_lane64(t_pos, 0), p1 = from_lane64(t_end, n - 1);
@@ -591,7 +592,7 @@ __global__ __launch_bounds__(FB) void k_tab_rows(const FormatTabArgs a, const ui
         // (a row that fits the stage holds its bases and qualities: the record is shorter than the stage)
         if (lane < n) {
             const uint32_t at = (uint32_t)(t_pos - a0) + t_nl + 1 + (a.print_seq ? t_len : 0) + 1 + (a.print_qual ? t_len : 0);
-            tab_row_tail(a, r0 + lane, t_len, stage + at);
+            tab_row_tail(a, r0 + lane, t_len64, stage + at);
         }
         for (uint32_t base = 0; base < n; base += GROUPS) {          // every lane takes part in the cross-lane reads
             const uint32_t i = base + grp < n ? base + grp : n - 1;

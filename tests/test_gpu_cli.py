@@ -256,6 +256,35 @@ def test_long_lines_and_long_reads(cli, oracle_cli, tmp_path):
     assert got[0] == want[0] == 0 and got[1] == want[1]
 
 
+def test_records_around_the_formatter_stage(cli, oracle_cli, tmp_path):
+    # The seq / fx2tab writers and the parser's line copy put the text of consecutive records together in an LDS
+    # stage (7 KiB of output, 3.5 KiB per plane) and fall back to direct writes for steps that do not fit:
+    # record sizes on both sides of those limits, mixed with empty and tiny records so that steps of every
+    # fill alternate with steps that do not fit, names longer than a chunk, FASTA in several widths and FASTQ.
+    import numpy as np
+    rng = np.random.default_rng(77)
+    sizes = [0, 1, 3, 15, 16, 17, 40, 150, 151, 1700, 3400, 3500, 3583, 3584, 3585, 3700, 6900, 7000, 7100, 7168, 7200, 14500]
+    fa, fq = tmp_path / "stage.fa", tmp_path / "stage.fq"
+    with open(fa, "wb") as fh, open(fq, "wb") as fh2:
+        for i in range(2500):
+            n = int(rng.choice(sizes)) if rng.random() < 0.3 else int(rng.integers(0, 400))
+            s = rng.choice(np.frombuffer(b"ACGTNacgtn-", np.uint8), size=n).tobytes()
+            q = rng.integers(33, 74, size=n, dtype=np.uint8).tobytes()
+            name = b"r%d %s" % (i, b"w" * int(rng.integers(0, 70)))
+            fh.write(b">" + name + b"\n")
+            for a in range(0, n, 80):
+                fh.write(s[a:a + 80] + b"\n")
+            if n:
+                fh2.write(b"@" + name + b"\n" + s + b"\n+\n" + q + b"\n")
+    for f in (fa, fq):
+        for argv in (["seq"], ["seq", "-w", "0"], ["seq", "-r", "-p", "-w", "61"], ["seq", "-n"], ["seq", "-n", "-i"], ["seq", "-s", "-w", "16"],
+                     ["seq", "-m", "3500"], ["seq", "-M", "3584", "-w", "7000"], ["seq", "--batch-bytes", "70000"],
+                     ["fx2tab"], ["fx2tab", "-n", "-l", "-g", "-B", "AT"], ["fx2tab", "-l", "-G", "-a"], ["stats", "-a", "-T"]):
+            want = run_cli(oracle_cli, [a for a in argv if a not in ("--batch-bytes", "70000")] + [str(f)])
+            got = run_cli(cli, argv + [str(f)])
+            assert got[0] == want[0] == 0 and got[1] == want[1], (f.name, argv)
+
+
 SEQ_EDIT_FLAGS = [["-g"], ["-g", "-u"], ["-g", "-G", "N-"], ["-r", "-p", "-g"], ["-l"], ["-u", "-r"], ["--dna2rna"],
                   ["--rna2dna"], ["--rna2dna", "-p", "-u"], ["--dna2rna", "-s", "-w", "0"], ["-g", "-m", "100", "-M", "160"],
                   ["-g", "-G", "ACGTUacgtu", "-m", "60"], ["-g", "-q"], ["-l", "-n"], ["-g", "-r", "-p", "-l", "--dna2rna"]]
