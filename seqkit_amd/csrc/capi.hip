@@ -112,11 +112,13 @@ skh::LaunchCfg cfg_for(const skh_ctx* ctx, uint64_t nrec, uint64_t total)
     c.use_hint = ctx->use_hint;
     if (ctx->force_logG >= 0) {
         c.logG = c.logG_count = ctx->force_logG > 6 ? 6 : ctx->force_logG;
+        c.count_u = ctx->count_u ? ctx->count_u : 3;
         c.use_hint = 0;
         return c;
     }
     c.logG = skh::lanes_log2_reverse(mean_len);
-    c.logG_count = skh::lanes_log2_count(mean_len);
+    c.count_u = ctx->count_u ? ctx->count_u : skh::count_chunks_per_lane(mean_len);      // SKH_COUNT_U overrides
+    c.logG_count = skh::lanes_log2_count(mean_len, c.count_u);
     return c;
 }
 
@@ -190,6 +192,8 @@ int skh_init(int device, skh_ctx** out)
     c->staged_steps = (uint32_t)env_int("SKH_STAGED_STEPS", 0);
     c->short_steps = (uint32_t)env_int("SKH_SHORT_STEPS", 0);
     c->count_steps = (uint32_t)env_int("SKH_COUNT_STEPS", 0);
+    c->count_u = env_int("SKH_COUNT_U", 0);
+    if (c->count_u < 3 || c->count_u > 5) c->count_u = 0;
     c->stats_steps = (uint32_t)env_int("SKH_STATS_STEPS", 0);
     e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->d_hints), N_SLOTS * sizeof(skh::BatchHint));

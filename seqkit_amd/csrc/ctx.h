@@ -26,6 +26,7 @@ struct skh_ctx {
     uint32_t staged_steps = 0;
     uint32_t short_steps = 0;
     uint32_t count_steps = 0;
+    int count_u = 0;         // chunks per lane and round of the counting kernel (0: from the mean record length)
     uint32_t stats_steps = 0;
 };
 

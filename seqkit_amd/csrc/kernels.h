@@ -15,7 +15,8 @@ struct StatsPartial { int64_t num, len_sum, gap_sum, len_min, len_max; };
 
 struct LaunchCfg {
     int logG;            // log2 of lanes per record in the short kernels (0..6), from the batch's mean length
-    int logG_count;      // the same for the counting kernel (a lane takes more chunks there)
+    int logG_count;      // the same for the counting kernel (a lane takes more chunks there: count_u of them per round)
+    int count_u;
     int use_hint;        // 1: the short kernels lower logG to what the sampled short records ask for
                          // (batches of short reads with a few very long records among them)
     uint32_t max_grid;   // optional cap on workgroups of a grid-stride launch (0 = none)
@@ -50,12 +51,28 @@ __host__ __device__ inline int lanes_log2_reverse(uint64_t mean)
     while (lg < 6 && (1ull << lg) < lanes) lg++;
     return lg;
 }
-__host__ __device__ inline int lanes_log2_count(uint64_t mean)
+// Counting kernel: a lane takes U chunks per round (all loaded before the first lookup), G = 2^k lanes serve
+// a record.  U is chosen (3, 4 or 5) so that G * U holds a record of the mean length in one round with the
+// fewest idle chunk slots: 100-base reads 2 lanes x 4 chunks, 150 bases 4 x 3, 250 bases 4 x 5.
+__host__ __device__ inline int lanes_log2_count(uint64_t mean, int U)
 {
-    const uint64_t chunks = (mean + 15) / 16 + 1, lanes = chunks <= 9 ? (chunks + 4) / 5 : (chunks + 5) / 5;
+    const uint64_t chunks = (mean + 15) / 16 + 1, lanes = (chunks + (uint64_t)U - 1) / (uint64_t)U;
     int lg = 0;
     while (lg < 6 && (1ull << lg) < lanes) lg++;
     return lg;
+}
+inline int count_chunks_per_lane(uint64_t mean)
+{
+    const uint64_t chunks = (mean + 15) / 16 + 1;
+    if (chunks > 80) return 3;          // records of kilobytes take several rounds anyway: measured best with 3
+    int best = 3;
+    uint64_t best_waste = ~0ull;
+    for (int U = 3; U <= 5; U++) {
+        const uint64_t slots = ((uint64_t)U) << lanes_log2_count(mean, U);
+        const uint64_t waste = slots >= chunks ? slots - chunks : ~0ull - 1;      // (more than 64 lanes' worth: several rounds)
+        if (waste < best_waste) { best_waste = waste; best = U; }
+    }
+    return best;
 }
 
 // lut == nullptr: reverse only.  qin/qout == nullptr: no quality plane.  hint: device scratch of this

@@ -23,6 +23,7 @@
 #include <stdint.h>
 
 #include <mutex>
+#include <type_traits>
 #include <unordered_map>
 
 #include "kernels.h"
@@ -116,13 +117,13 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_prepare(const uint64_t* __restric
 
 // log2 of the lanes per record a short kernel works with: the host's choice, lowered to what the
 // sampled short records ask for (never raised: the grid was sized for the host's choice).
-template <bool COUNT>
+template <bool COUNT, int U = 3>
 __device__ __forceinline__ int hinted_logG(int logG_host, uint32_t mean_short, int use_hint)
 {
     if (!use_hint) return logG_host;
     const uint32_t mean = __builtin_amdgcn_readfirstlane(mean_short);
     if (mean == ~0u) return logG_host;
-    const int lg = COUNT ? lanes_log2_count(mean) : lanes_log2_reverse(mean);
+    const int lg = COUNT ? lanes_log2_count(mean, U) : lanes_log2_reverse(mean);
     return lg < logG_host ? lg : logG_host;
 }
 
@@ -1344,7 +1345,7 @@ __device__ __forceinline__ uint32_t field16(const uint32_t* acc16, uint32_t c)
     return (c & 2u) ? (w >> 16) : (w & 0xffffu);
 }
 
-template <int NW>
+template <int NW, int U>
 __global__ __launch_bounds__(SKH_BLOCK) void k_count_short(
     const uint8_t* __restrict__ seq, const uint64_t* __restrict__ offs, uint64_t nrec, uint64_t total,
     Table256 cls, uint32_t nclass, int logG_host, uint32_t steps, uint32_t neutral, uint64_t* __restrict__ counts,
@@ -1354,8 +1355,7 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_count_short(
     const uint32_t mean_short = hint->mean_short;        // asked for before the table set-up, needed after it
     count_lds_init<NW>(L, cls);
     uint32_t* n_long = &hint->n_long;
-    const int logG = hinted_logG<true>(logG_host, mean_short, use_hint);
-    constexpr int U = 3;
+    const int logG = hinted_logG<true, U>(logG_host, mean_short, use_hint);
     const bool has_neutral = neutral < 256u;
     const uint32_t neutral4 = (neutral & 0xffu) * 0x01010101u;
     const uint32_t G = 1u << logG, j = threadIdx.x & (G - 1);
@@ -1988,14 +1988,23 @@ hipError_t launch_count(const LaunchCfg& cfg, const uint8_t* seq, const uint64_t
     if (g1 > 0x7fffffffull || g2 > 0x7fffffffull) return hipErrorInvalidValue;
     hipError_t e = launch_prepare(offs, nrec, hint, st);
     if (e != hipSuccess) return e;
+    auto short_kernel = [&](auto nw, auto u) {
+        hipLaunchKernelGGL((k_count_short<decltype(nw)::value, decltype(u)::value>), dim3((uint32_t)g1), dim3(SKH_BLOCK), 0, st, seq,
+                           offs, nrec, total, cls, nclass, cfg.logG_count, steps, neutral, counts, hint, cfg.use_hint);
+    };
+    auto with_u = [&](auto nw) {
+        switch (cfg.count_u) {
+        case 4: short_kernel(nw, std::integral_constant<int, 4>{}); break;
+        case 5: short_kernel(nw, std::integral_constant<int, 5>{}); break;
+        default: short_kernel(nw, std::integral_constant<int, 3>{}); break;
+        }
+    };
     if (nclass <= 4) {
-        hipLaunchKernelGGL((k_count_short<1>), dim3((uint32_t)g1), dim3(SKH_BLOCK), 0, st, seq, offs, nrec, total,
-                           cls, nclass, cfg.logG_count, steps, neutral, counts, hint, cfg.use_hint);
+        with_u(std::integral_constant<int, 1>{});
         if (g2) hipLaunchKernelGGL((k_count_tiles<1>), dim3((uint32_t)g2), dim3(SKH_BLOCK), 0, st, seq, offs, nrec, total,
                                    cls, nclass, neutral, counts, hint);
     } else {
-        hipLaunchKernelGGL((k_count_short<2>), dim3((uint32_t)g1), dim3(SKH_BLOCK), 0, st, seq, offs, nrec, total,
-                           cls, nclass, cfg.logG_count, steps, neutral, counts, hint, cfg.use_hint);
+        with_u(std::integral_constant<int, 2>{});
         if (g2) hipLaunchKernelGGL((k_count_tiles<2>), dim3((uint32_t)g2), dim3(SKH_BLOCK), 0, st, seq, offs, nrec, total,
                                    cls, nclass, neutral, counts, hint);
     }

@@ -180,11 +180,14 @@ def test_inplace_twice_is_identity(lib, ctx_default, ora):
     assert np.array_equal(twice_s, seq) and np.array_equal(twice_q, qual)
 
 
+@pytest.mark.parametrize("count_u", ["3", "4", "5"])
 @pytest.mark.parametrize("logg", range(7))
-def test_every_group_width(lib, ora, logg, monkeypatch):
-    # the lanes-per-record choice is a speed knob: every width must give the same bytes
+def test_every_group_width(lib, ora, logg, count_u, monkeypatch):
+    # the lanes-per-record choice and the chunks a lane of the counting kernel takes per round are speed knobs:
+    # every combination must give the same bytes
     monkeypatch.setenv("SKH_LOGG", str(logg))
     monkeypatch.setenv("SKH_SPAN_U", "0")
+    monkeypatch.setenv("SKH_COUNT_U", count_u)
     c = lib.init(0)
     try:
         lengths = np.concatenate([CASES["ragged0_300"][:700], [40000, 0, 33000, 17], CASES["tiny0_20"][:300],
