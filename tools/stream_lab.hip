@@ -342,7 +342,9 @@ int main(int argc, char** argv)
     };
     char name[128];
     const uint64_t n16 = total / 16;
+    const bool only_lines = argc > 1;
     for (int bpc : {4, 8, 16}) {
+        if (only_lines) break;
         const int grid = 256 * bpc;
         snprintf(name, sizeof name, "plain U=1 grid=%d", grid);
         timeit(name, [&] { hipLaunchKernelGGL(k_plain<1>, dim3(grid), dim3(256), 0, 0, (const uint4*)in, (uint4*)out, n16); });
@@ -355,6 +357,7 @@ int main(int argc, char** argv)
                [&] { hipLaunchKernelGGL(k_plain<1>, dim3(grid), dim3(256), 0, 0, (const uint4*)in, (uint4*)out, n16); });
     }
     for (uint32_t S : {2400u, 3072u, 4800u}) {
+        if (only_lines) break;
         const uint64_t nsteps = total / S;
         check_len = nsteps * S;
         for (int bpc : {4, 6, 8}) {
@@ -373,6 +376,7 @@ int main(int argc, char** argv)
         }
     }
     for (uint32_t S : {2400u, 3072u}) {
+        if (only_lines) break;
         const uint64_t nsteps = total / S;
         check_len = nsteps * S;
         for (int bpc : {3, 4, 5}) {
@@ -418,6 +422,19 @@ int main(int argc, char** argv)
         }
     }
 
+    // stretches that start on 128-byte lines (2304, 2432) against stretches that do not (2400, 2416): what the
+    // partial lines at either end of a wavefront's run cost
+    for (uint32_t S : {2304u, 2400u, 2416u, 2432u}) {
+        const uint64_t nsteps = total / S;
+        check_len = nsteps * S;
+        const uint32_t logK = 1;
+        const uint64_t nseg = (nsteps + (4ull << logK) - 1) / (4ull << logK);
+        for (int rep = 0; rep < 2; rep++) {
+            snprintf(name, sizeof name, "lines: seg NB=2 K=2 S=%u grid=%d", S, (int)nseg);
+            timeit(name, [&] { hipLaunchKernelGGL((k_wave_seg<3, 2>), dim3((int)nseg), dim3(256), 0, 0, in, out, nsteps, S, logK); });
+        }
+    }
+    if (argc > 1) { printf("done\n"); return 0; }
     {
         check_len = 0;
         const uint64_t nrec = 10000000, L = 150;
