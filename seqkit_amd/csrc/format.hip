@@ -241,6 +241,10 @@ __device__ __forceinline__ uint32_t fmt_records_per_step(uint64_t total, uint64_
     return r < 1 ? 1u : (r > 64 ? 64u : (uint32_t)r);
 }
 
+// Records (rows) far beyond the stage on average: the staged writers leave at once and the direct kernels
+// take every record.
+__device__ __forceinline__ bool all_steps_direct(uint64_t total, uint64_t nrec) { return nrec != 0 && total / nrec > 4 * FW_STAGE; }
+
 // true when the writer that puts rows together in LDS left the step of record r to the direct kernels
 __device__ __forceinline__ bool step_is_direct(uint64_t r, uint32_t R, uint64_t nrec, const uint64_t* __restrict__ pos,
                                                const uint64_t* __restrict__ size)
@@ -262,6 +266,10 @@ __global__ __launch_bounds__(FB) void k_fmt_write(const FormatSeqArgs a, const u
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t R = fmt_records_per_step(tot, a.nrec);
     const uint64_t nsteps = (a.nrec + R - 1) / R;
+    if (all_steps_direct(tot, a.nrec)) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) *n_direct = 1u;
+        return;
+    }
     const Div32 div(a.width);
     uint8_t* stage = s_stage[wave];
     for (uint64_t step = (uint64_t)blockIdx.x * (FB / 64) + wave; step < nsteps; step += (uint64_t)gridDim.x * (FB / 64)) {
@@ -280,7 +288,7 @@ __global__ __launch_bounds__(FB) void k_fmt_write(const FormatSeqArgs a, const u
         const uint64_t p0 = from_lane64(t_pos, 0), p1 = from_lane64(t_end, n - 1);
         const uint64_t a0 = p0 & ~15ull;
         if (p1 - a0 > FW_STAGE) {                          // wave-uniform
-            if (lane == 0) atomicAdd(n_direct, 1u);
+            if (lane == 0) *n_direct = 1u;                 // (every writer stores the same value)
             continue;
         }
         const uint32_t t_size = (uint32_t)(t_end - t_pos);
@@ -317,12 +325,13 @@ __global__ __launch_bounds__(FB) void k_fmt_write_direct(const FormatSeqArgs a, 
     const uint32_t j = threadIdx.x & (G - 1);
     const uint32_t leader = (threadIdx.x & 63) & ~(G - 1);
     const uint32_t R = fmt_records_per_step(tot, a.nrec);
+    const bool all_direct = all_steps_direct(tot, a.nrec);
     const Div64 div{a.width};
     for (uint64_t r = ((uint64_t)blockIdx.x * FB + threadIdx.x) / G; r < a.nrec; r += (uint64_t)gridDim.x * (FB / G)) {
         uint64_t m_size = 0, m_pos = 0, m_s = 0, m_e = 0, m_name = 0;
         uint32_t m_nl = 0;
         if (j == 0) {
-            if (step_is_direct(r, R, a.nrec, pos, size)) m_size = size[r];
+            if (all_direct || step_is_direct(r, R, a.nrec, pos, size)) m_size = size[r];
             if (m_size != 0) {
                 m_pos = pos[r]; m_s = a.offsets[r]; m_e = a.offsets[r + 1];
                 if (a.print_name) { m_nl = shown_name[r]; m_name = a.name_pos[r]; }
@@ -570,6 +579,10 @@ __global__ __launch_bounds__(FB) void k_tab_rows(const FormatTabArgs a, const ui
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t R = fmt_records_per_step(tot, a.nrec);
     const uint64_t nsteps = (a.nrec + R - 1) / R;
+    if (all_steps_direct(tot, a.nrec)) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) *n_direct = 1u;
+        return;
+    }
     uint8_t* stage = s_stage[wave];
     for (uint64_t step = (uint64_t)blockIdx.x * (FB / 64) + wave; step < nsteps; step += (uint64_t)gridDim.x * (FB / 64)) {
         const uint64_t r0 = step * R;
@@ -586,7 +599,7 @@ __global__ __launch_bounds__(FB) void k_tab_rows(const FormatTabArgs a, const ui
         const uint64_t p0 = from_lane64(t_pos, 0), p1 = from_lane64(t_end, n - 1);
         const uint64_t a0 = p0 & ~15ull;
         if (p1 - a0 > FW_STAGE) {                          // wave-uniform
-            if (lane == 0) atomicAdd(n_direct, 1u);
+            if (lane == 0) *n_direct = 1u;                 // (every writer stores the same value)
             continue;
         }
         // (a row that fits the stage holds its bases and qualities: the record is shorter than the stage)
@@ -633,10 +646,11 @@ __global__ __launch_bounds__(FB) void k_tab_write(const FormatTabArgs a, const u
     const uint32_t j = threadIdx.x & (G - 1);
     const uint32_t leader = (threadIdx.x & 63) & ~(G - 1);
     const uint32_t R = fmt_records_per_step(tot, a.nrec);
+    const bool all_direct = all_steps_direct(tot, a.nrec);
     for (uint64_t r = ((uint64_t)blockIdx.x * FB + threadIdx.x) / G; r < a.nrec; r += (uint64_t)gridDim.x * (FB / G)) {
         uint64_t m_pos = 0, m_s = 0, m_e = 0, m_name = 0;
         uint32_t m_nl = 0, m_take = 0;
-        if (j == 0 && step_is_direct(r, R, a.nrec, pos, size)) {
+        if (j == 0 && (all_direct || step_is_direct(r, R, a.nrec, pos, size))) {
             m_take = 1; m_pos = pos[r]; m_s = a.offsets[r]; m_e = a.offsets[r + 1]; m_nl = shown_name[r]; m_name = a.name_pos[r];
         }
         if (__shfl(m_take, leader) == 0) continue;
@@ -664,8 +678,9 @@ __global__ __launch_bounds__(FB) void k_tab_numbers(const FormatTabArgs a, const
     const uint64_t tot = *total;
     if (*n_direct == 0 || tot > out_capacity) return;
     const uint32_t R = fmt_records_per_step(tot, a.nrec);
+    const bool all_direct = all_steps_direct(tot, a.nrec);
     for (uint64_t r = (uint64_t)blockIdx.x * FB + threadIdx.x; r < a.nrec; r += (uint64_t)gridDim.x * FB) {
-        if (!step_is_direct(r, R, a.nrec, pos, size)) continue;
+        if (!all_direct && !step_is_direct(r, R, a.nrec, pos, size)) continue;
         const uint64_t len = a.offsets[r + 1] - a.offsets[r];
         tab_row_tail(a, r, len, out + pos[r] + shown_name[r] + 1 + (a.print_seq ? len : 0) + 1 + (a.print_qual ? len : 0));
     }
