@@ -225,6 +225,111 @@ __device__ __forceinline__ void write_record_text(const FormatSeqArgs& a, uint8_
     }
 }
 
+__device__ __forceinline__ uint32_t wave_max32(uint32_t v)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)v, d); v = t > v ? t : v; }
+    return v;
+}
+
+// One 16-byte piece (bytes [p, p + 16) of a field of L bytes, p < L) to its place: plain, or with a '\n' after
+// every `width` bytes but the last line (the piece that holds the base before a break writes the break).
+// The end of a field goes as its last 16 bytes once more (same values); fields under 16 bytes byte by byte.
+__device__ __forceinline__ void copy_piece(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, uint32_t L, uint32_t p,
+                                           bool wrapped, const Div32& div)
+{
+    if (!wrapped) {
+        if (p + 16 <= L) copy16(dst + p, src + p);
+        else if (L >= 16) copy16(dst + L - 16, src + L - 16);
+        else for (uint32_t k = p; k < L; k++) dst[k] = src[k];
+        return;
+    }
+    const uint32_t width = div.width;
+    const uint32_t last = p + 16 <= L ? p + 15 : L - 1;
+    const uint32_t l0 = div(p), l1 = div(last);
+    if (l0 == l1 && p + 16 <= L) {
+        copy16(dst + p + l0, src + p);
+    } else if (l1 == l0 + 1 && width >= 16 && (l0 + 1) * width >= 16 && (l0 + 1) * width + 16 <= L) {
+        const uint32_t b = (l0 + 1) * width;          // first base of the next line: the 16 bytes that end the line and
+        copy16(dst + b - 16 + l0, src + b - 16);      // the 16 that start the next one (overlaps carry the same values)
+        copy16(dst + b + l1, src + b);
+    } else {
+        for (uint32_t k = p; k <= last; k++) dst[k + div(k)] = src[k];
+    }
+    const uint32_t breaks = div(L - 1);
+    for (uint32_t b = l0 + 1; b <= breaks && b * width - 1 <= last; b++) dst[b * width + b - 1] = '\n';
+}
+
+// The text of the n records of a step (lane i holds record i: op = where its text starts in the stage, sz = its
+// size, 0 for a record that is not printed) put together in the stage.  The separators are written by the
+// record's own lane; the 16-byte pieces of names, bases and qualities of ALL records are dealt over the 64
+// lanes, field by field: a field gets PF piece slots per record (the most any record of the step needs), slot
+// q = lane + 64 k is piece q mod PF of record q / PF -- lanes are busy whatever a field's length, where 16
+// lanes per record keep about half their slots filled (a name is 3 pieces, a read 10).
+__device__ __forceinline__ void write_step_flat(const FormatSeqArgs& a, uint8_t* __restrict__ stage, uint32_t lane, uint32_t n,
+                                                const Div32& div, uint32_t op, uint32_t sz, uint32_t len, uint32_t nl,
+                                                uint64_t s, uint64_t name)
+{
+    const bool has = lane < n && sz != 0;
+    if (!has) { len = 0; nl = 0; }
+    const bool wrapped = a.width >= 1;
+    const bool with_qual = a.print_qual && a.qual != nullptr;
+    const uint32_t PN = wave_max32(a.print_name ? (nl + 15) >> 4 : 0u);
+    const uint32_t PS = wave_max32(a.print_seq ? (len + 15) >> 4 : 0u);
+    const uint32_t PQ = with_qual ? wave_max32((len + 15) >> 4) : 0u;
+    // where a record's fields start, from its name and sequence lengths
+    auto layout = [&](uint32_t nl_r, uint32_t len_r, uint32_t& o_name, uint32_t& o_seq, uint32_t& o_plus, uint32_t& o_qual,
+                      uint32_t& w) {
+        o_name = (a.print_name && a.print_seq) ? 1u : 0u;
+        o_seq = a.print_name ? o_name + nl_r + 1 : 0u;
+        w = (!wrapped || len_r == 0) ? len_r : len_r + div(len_r - 1);
+        o_plus = o_seq + (a.print_seq ? w + 1 : 0u);
+        o_qual = o_plus + (a.plus_line ? 2u : 0u);
+    };
+    if (has) {
+        uint32_t o_name, o_seq, o_plus, o_qual, w;
+        layout(nl, len, o_name, o_seq, o_plus, o_qual, w);
+        uint8_t* o = stage + op;
+        if (a.print_name) {
+            if (a.print_seq) o[0] = (a.empty_fasta && len == 0) ? (uint8_t)'>' : a.mark;
+            o[o_name + nl] = '\n';
+        }
+        if (a.print_seq) o[o_seq + w] = '\n';
+        if (a.print_qual && !(a.empty_fasta && len == 0)) {
+            if (a.plus_line) { o[o_plus] = '+'; o[o_plus + 1] = '\n'; }
+            o[o_qual + (a.qual ? w : 0u)] = '\n';
+        }
+    }
+    const uint64_t s0 = from_lane64(s, 0);               // sequences of a step lie within 4 GiB of each other
+    const uint32_t s_rel = (uint32_t)(s - s0);
+    // field by field, so that the lanes of one instruction read one kind of source: slot q = lane + 64 k of a
+    // field with PF slots per record is piece q mod PF of record q / PF
+#pragma unroll 1
+    for (int f = 0; f < 3; f++) {
+        const uint32_t PF = f == 0 ? PN : (f == 1 ? PS : PQ);
+        if (PF == 0) continue;
+        const Div32 by_pf(PF);
+        const uint32_t nslots = n * PF;
+        for (uint32_t q0 = 0; q0 < nslots; q0 += 64) {        // every lane takes part in the cross-lane reads
+            const uint32_t q = q0 + lane < nslots ? q0 + lane : nslots - 1;
+            const uint32_t r = by_pf(q), k = q - r * PF;
+            const uint32_t op_r = (uint32_t)__shfl((int)op, (int)r), len_r = (uint32_t)__shfl((int)len, (int)r);
+            const uint32_t nl_r = (uint32_t)__shfl((int)nl, (int)r);
+            uint32_t o_name, o_seq, o_plus, o_qual, w;
+            layout(nl_r, len_r, o_name, o_seq, o_plus, o_qual, w);
+            uint8_t* o = stage + op_r;
+            if (f == 0) {
+                const uint64_t name_r = from_lane64(name, r);
+                if (q0 + lane < nslots && 16 * k < nl_r) copy_piece(o + o_name, a.text + name_r, nl_r, 16 * k, false, div);
+            } else {
+                const uint32_t srel_r = (uint32_t)__shfl((int)s_rel, (int)r);
+                if (q0 + lane < nslots && 16 * k < len_r)
+                    copy_piece(o + (f == 1 ? o_seq : o_qual), (f == 1 ? a.seq : a.qual) + s0 + srel_r, len_r, 16 * k, wrapped, div);
+            }
+        }
+    }
+}
+
 // The output text of consecutive records is one contiguous stretch.  A wavefront takes as many records
 // per step as fit its LDS stage (from the mean record size, at most 64), puts their text together there
 // -- the pieces of a record start at any byte, which costs LDS next to nothing, while every misaligned
@@ -258,11 +363,10 @@ __global__ __launch_bounds__(FB) void k_fmt_write(const FormatSeqArgs a, const u
                                                   const uint64_t* __restrict__ total, uint32_t* __restrict__ n_direct,
                                                   uint8_t* __restrict__ out, uint64_t out_capacity)
 {
-    constexpr uint32_t G = 16, GROUPS = 64 / G;
     __shared__ __attribute__((aligned(16))) uint8_t s_stage[FB / 64][FW_STAGE + 32];
     const uint64_t tot = *total;
     if (tot > out_capacity) return;
-    const uint32_t lane = threadIdx.x & 63, j = lane & (G - 1), grp = lane / G;
+    const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t R = fmt_records_per_step(tot, a.nrec);
     const uint64_t nsteps = (a.nrec + R - 1) / R;
@@ -293,14 +397,7 @@ __global__ __launch_bounds__(FB) void k_fmt_write(const FormatSeqArgs a, const u
         }
         const uint32_t t_size = (uint32_t)(t_end - t_pos);
         if (p1 == p0) continue;
-        for (uint32_t base = 0; base < n; base += GROUPS) {          // every lane takes part in the cross-lane reads
-            const uint32_t i = base + grp < n ? base + grp : n - 1;
-            const uint32_t sz = (uint32_t)__shfl((int)t_size, (int)i), len = (uint32_t)__shfl((int)t_len, (int)i);
-            const uint32_t nl = (uint32_t)__shfl((int)t_nl, (int)i);
-            const uint64_t p = from_lane64(t_pos, i), s = from_lane64(t_s, i), name = from_lane64(t_name, i);
-            if (base + grp < n && sz != 0)
-                write_record_text<G, uint32_t, Div32>(a, stage + (uint32_t)(p - a0), s, len, nl, name, div, j);
-        }
+        write_step_flat(a, stage, lane, n, div, (uint32_t)(t_pos - a0), t_size, t_len, t_nl, t_s, t_name);
         __builtin_amdgcn_wave_barrier();
         const uint32_t nbytes = (uint32_t)(p1 - a0), head = (uint32_t)(p0 - a0);
         const uint32_t c_lo = head ? 16u : 0u, c_hi = nbytes & ~15u;
