@@ -668,11 +668,10 @@ __global__ __launch_bounds__(FB) void k_tab_rows(const FormatTabArgs a, const ui
                                                  const uint64_t* __restrict__ total, uint32_t* __restrict__ n_direct,
                                                  uint8_t* __restrict__ out, uint64_t out_capacity)
 {
-    constexpr uint32_t G = 16, GROUPS = 64 / G;
     __shared__ __attribute__((aligned(16))) uint8_t s_stage[FB / 64][FW_STAGE + 32];
     const uint64_t tot = *total;
     if (tot > out_capacity) return;
-    const uint32_t lane = threadIdx.x & 63, j = lane & (G - 1), grp = lane / G;
+    const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t R = fmt_records_per_step(tot, a.nrec);
     const uint64_t nsteps = (a.nrec + R - 1) / R;
@@ -704,19 +703,39 @@ __global__ __launch_bounds__(FB) void k_tab_rows(const FormatTabArgs a, const ui
             const uint32_t at = (uint32_t)(t_pos - a0) + t_nl + 1 + (a.print_seq ? t_len : 0) + 1 + (a.print_qual ? t_len : 0);
             tab_row_tail(a, r0 + lane, t_len64, stage + at);
         }
-        for (uint32_t base = 0; base < n; base += GROUPS) {          // every lane takes part in the cross-lane reads
-            const uint32_t i = base + grp < n ? base + grp : n - 1;
-            const uint32_t len = (uint32_t)__shfl((int)t_len, (int)i), nl = (uint32_t)__shfl((int)t_nl, (int)i);
-            const uint64_t p = from_lane64(t_pos, i), s = from_lane64(t_s, i), name = from_lane64(t_name, i);
-            if (base + grp < n) {
-                uint8_t* o = stage + (uint32_t)(p - a0);
-                copy_plain<G, uint32_t>(o, a.text + name, nl, j);
-                if (j == 0) o[nl] = '\t';
-                o += nl + 1;
-                if (a.print_seq) { copy_plain<G, uint32_t>(o, a.seq + s, len, j); o += len; }
-                if (j == 0) *o = '\t';
-                o++;
-                if (a.print_qual) copy_plain<G, uint32_t>(o, a.qual + s, len, j);
+        // the tabs by each record's own lane; the 16-byte pieces of names, bases and qualities of all rows dealt
+        // over the 64 lanes, field by field (see write_step_flat)
+        const uint32_t op = (uint32_t)(t_pos - a0);
+        const uint32_t f_len = lane < n ? t_len : 0u, f_nl = lane < n ? t_nl : 0u;
+        if (lane < n) {
+            stage[op + t_nl] = '\t';
+            stage[op + t_nl + 1 + (a.print_seq ? t_len : 0u)] = '\t';
+        }
+        const uint64_t s0 = from_lane64(t_s, 0);
+        const uint32_t s_rel = (uint32_t)(t_s - s0);
+        const Div32 no_wrap(0);
+#pragma unroll 1
+        for (int f = 0; f < 3; f++) {
+            if ((f == 1 && !a.print_seq) || (f == 2 && !a.print_qual)) continue;
+            const uint32_t PF = wave_max32(((f == 0 ? f_nl : f_len) + 15) >> 4);
+            if (PF == 0) continue;
+            const Div32 by_pf(PF);
+            const uint32_t nslots = n * PF;
+            for (uint32_t q0 = 0; q0 < nslots; q0 += 64) {            // every lane takes part in the cross-lane reads
+                const uint32_t q = q0 + lane < nslots ? q0 + lane : nslots - 1;
+                const uint32_t r = by_pf(q), k = q - r * PF;
+                const uint32_t op_r = (uint32_t)__shfl((int)op, (int)r), len_r = (uint32_t)__shfl((int)f_len, (int)r);
+                const uint32_t nl_r = (uint32_t)__shfl((int)f_nl, (int)r);
+                uint8_t* o = stage + op_r;
+                if (f == 0) {
+                    const uint64_t name_r = from_lane64(t_name, r);
+                    if (q0 + lane < nslots && 16 * k < nl_r) copy_piece(o, a.text + name_r, nl_r, 16 * k, false, no_wrap);
+                } else {
+                    const uint32_t srel_r = (uint32_t)__shfl((int)s_rel, (int)r);
+                    const uint32_t at = nl_r + 1 + (f == 2 ? (a.print_seq ? len_r : 0u) + 1 : 0u);
+                    if (q0 + lane < nslots && 16 * k < len_r)
+                        copy_piece(o + at, (f == 1 ? a.seq : a.qual) + s0 + srel_r, len_r, 16 * k, false, no_wrap);
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();
