@@ -577,15 +577,51 @@ __global__ __launch_bounds__(PB) void k_parse_copy(const ParseState* st, uint64_
         if (FASTQ && last > 0) { const uint64_t e2 = shfl64(t_end, last - 1); p1 = e2 > p1 ? e2 : p1; }
         const uint64_t a0 = p0 & ~15ull;
         const bool staged = !__any(valid && t_len > LONG_LINE) && p1 - a0 <= PC_STAGE;
-        for (uint32_t base = 0; base <= last; base += GROUPS) {       // every lane takes part in the cross-lane reads
-            const uint32_t i = base + grp;
-            const uint32_t len = (uint32_t)__shfl((int)t_len, (int)i), q = (uint32_t)__shfl((int)t_q, (int)i);
-            const uint64_t dst = shfl64(t_dst, i), start = shfl64(t_start, i);
-            if (len == 0 || len > LONG_LINE) continue;                 // (an item that is not valid has len 0)
-            if (staged) copy_line<G>(s_stage[wave][FASTQ ? q : 0] + (uint32_t)(dst - a0), text + start, len, j);
-            else copy_line<G>((FASTQ && q ? qual : seq) + dst, text + start, len, j);
+        if (!staged) {
+            for (uint32_t base = 0; base <= last; base += GROUPS) {   // every lane takes part in the cross-lane reads
+                const uint32_t i = base + grp;
+                const uint32_t len = (uint32_t)__shfl((int)t_len, (int)i), q = (uint32_t)__shfl((int)t_q, (int)i);
+                const uint64_t dst = shfl64(t_dst, i), start = shfl64(t_start, i);
+                if (len == 0 || len > LONG_LINE) continue;             // (an item that is not valid has len 0)
+                copy_line<G>((FASTQ && q ? qual : seq) + dst, text + start, len, j);
+            }
+            continue;
         }
-        if (!staged) continue;
+        // The 16-byte pieces of all lines of the step dealt over the 64 lanes: a line gets PF piece slots (the
+        // most any line of the step needs), slot q = lane + 64 k is piece q mod PF of line q / PF -- lanes are busy
+        // whatever the line length, where 8 lanes per line leave six of sixteen slots empty on a 150-base read.
+        // (FASTQ: the bases and the qualities of a record are neighbours in the text and stay neighbours in an
+        // instruction; which stage a piece goes to is the parity of its line.)
+        const uint32_t d_rel = (uint32_t)(t_dst - a0);              // (0-length items never use theirs)
+        const uint64_t start0 = shfl64(t_start, first);
+        const uint32_t st_rel = (uint32_t)(t_start - start0);        // the lines of a step lie within 4 GiB of text
+        uint32_t PF = (t_len + 15) >> 4;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)PF, d); PF = t > PF ? t : PF; }
+        if (PF != 0) {
+            const uint32_t nslots = (last + 1) * PF;
+            const uint32_t magic = PF > 1 ? (uint32_t)((0x100000000ull + PF - 1) / PF) : 0u;   // q / PF for q < 2^16
+            for (uint32_t q0 = 0; q0 < nslots; q0 += 64) {            // every lane takes part in the cross-lane reads
+                const uint32_t q = q0 + lane < nslots ? q0 + lane : nslots - 1;
+                const uint32_t r = PF > 1 ? __umulhi(q, magic) : q, k = q - r * PF;
+                const uint32_t len = (uint32_t)__shfl((int)t_len, (int)r), dr = (uint32_t)__shfl((int)d_rel, (int)r);
+                const uint32_t sr = (uint32_t)__shfl((int)st_rel, (int)r);
+                const uint32_t p = 16 * k;
+                if (q0 + lane >= nslots || p >= len) continue;
+                uint8_t* out = s_stage[wave][FASTQ ? (r & 1u) : 0u] + dr;
+                const uint8_t* src = text + start0 + sr;
+                uint4 v;
+                if (p + 16 <= len) {
+                    __builtin_memcpy(&v, src + p, 16);
+                    __builtin_memcpy(out + p, &v, 16);
+                } else if (len >= 16) {                               // the last 16 bytes again: same values, no byte loop
+                    __builtin_memcpy(&v, src + len - 16, 16);
+                    __builtin_memcpy(out + len - 16, &v, 16);
+                } else {
+                    for (uint32_t b = p; b < len; b++) out[b] = src[b];
+                }
+            }
+        }
         __builtin_amdgcn_wave_barrier();
         const uint32_t nbytes = (uint32_t)(p1 - a0), head = (uint32_t)(p0 - a0);
         const uint32_t c_lo = head ? 16u : 0u, c_hi = nbytes & ~15u;
