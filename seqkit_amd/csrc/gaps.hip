@@ -36,11 +36,13 @@ __device__ __forceinline__ uint32_t keep_mask(uint4 v, uint64_t o, uint64_t tota
     return m;
 }
 
+// kept bytes per tile.  Only the number matters here, so the bytes go through a table of 0 / 1 words and
+// are added up (one shift, one LDS read and half an add per byte) instead of being assembled into a mask.
 __global__ __launch_bounds__(GAPB) void k_gap_tile_count(const uint8_t* __restrict__ seq, uint64_t total, Table256 is_gap,
                                                          uint64_t* __restrict__ tile_kept)
 {
-    __shared__ uint8_t s_gap[256];
-    s_gap[threadIdx.x] = is_gap.v[threadIdx.x];
+    __shared__ uint32_t s_keep[256];
+    s_keep[threadIdx.x] = is_gap.v[threadIdx.x] ? 0u : 1u;
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t ntile = (total + GTILE - 1) / GTILE;
@@ -48,7 +50,15 @@ __global__ __launch_bounds__(GAPB) void k_gap_tile_count(const uint8_t* __restri
     if (tile >= ntile) return;
     const uint64_t o = tile * GTILE + 16ull * lane;
     uint32_t c = 0;
-    if (o < total) c = (uint32_t)__builtin_popcount(keep_mask(ld16(seq + o), o, total, s_gap));
+    if (o + 16 <= total) {
+        const uint4 v = ld16(seq + o);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int d = 0; d < 4; d++)
+            c += s_keep[w[d] & 0xffu] + s_keep[(w[d] >> 8) & 0xffu] + s_keep[(w[d] >> 16) & 0xffu] + s_keep[w[d] >> 24];
+    } else if (o < total) {                              // the chunk that straddles the end of the plane
+        for (uint64_t p = o; p < total; p++) c += s_keep[seq[p]];
+    }
     for (int d = 1; d < 64; d <<= 1) c += __shfl_xor(c, d);
     if (lane == 0) tile_kept[tile] = c;
 }
