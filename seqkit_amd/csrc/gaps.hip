@@ -21,6 +21,7 @@ namespace {
 
 constexpr int GAPB = 256;                 // threads per workgroup
 constexpr uint32_t GTILE = 1024;          // bytes per wavefront tile
+constexpr int GTPW = 4;                   // consecutive tiles a wavefront takes (a workgroup: 16 KiB of plane)
 
 // bit k of the result: byte k of the chunk at plane offset o is kept (inside the plane, not a gap)
 __device__ __forceinline__ uint32_t keep_mask(uint4 v, uint64_t o, uint64_t total, const uint8_t* s_gap)
@@ -46,21 +47,30 @@ __global__ __launch_bounds__(GAPB) void k_gap_tile_count(const uint8_t* __restri
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t ntile = (total + GTILE - 1) / GTILE;
-    const uint64_t tile = (uint64_t)blockIdx.x * (GAPB / 64) + (threadIdx.x >> 6);
-    if (tile >= ntile) return;
-    const uint64_t o = tile * GTILE + 16ull * lane;
-    uint32_t c = 0;
-    if (o + 16 <= total) {
-        const uint4 v = ld16(seq + o);
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    const uint64_t tile0 = ((uint64_t)blockIdx.x * (GAPB / 64) + (threadIdx.x >> 6)) * GTPW;     // GTPW tiles per wavefront
+    if (tile0 >= ntile) return;
+    uint4 v[GTPW];
 #pragma unroll
-        for (int d = 0; d < 4; d++)
-            c += s_keep[w[d] & 0xffu] + s_keep[(w[d] >> 8) & 0xffu] + s_keep[(w[d] >> 16) & 0xffu] + s_keep[w[d] >> 24];
-    } else if (o < total) {                              // the chunk that straddles the end of the plane
-        for (uint64_t p = o; p < total; p++) c += s_keep[seq[p]];
+    for (int t = 0; t < GTPW; t++) {                      // all loads before the first lookup
+        const uint64_t o = (tile0 + t) * GTILE + 16ull * lane;
+        v[t] = o + 16 <= total ? ld16(seq + o) : make_uint4(0, 0, 0, 0);
     }
-    for (int d = 1; d < 64; d <<= 1) c += __shfl_xor(c, d);
-    if (lane == 0) tile_kept[tile] = c;
+#pragma unroll
+    for (int t = 0; t < GTPW; t++) {
+        if (tile0 + t >= ntile) break;                   // wave-uniform
+        const uint64_t o = (tile0 + t) * GTILE + 16ull * lane;
+        uint32_t c = 0;
+        if (o + 16 <= total) {
+            const uint32_t w[4] = {v[t].x, v[t].y, v[t].z, v[t].w};
+#pragma unroll
+            for (int d = 0; d < 4; d++)
+                c += s_keep[w[d] & 0xffu] + s_keep[(w[d] >> 8) & 0xffu] + s_keep[(w[d] >> 16) & 0xffu] + s_keep[w[d] >> 24];
+        } else if (o < total) {                          // the chunk that straddles the end of the plane
+            for (uint64_t p = o; p < total; p++) c += s_keep[seq[p]];
+        }
+        for (int d = 1; d < 64; d <<= 1) c += __shfl_xor(c, d);
+        if (lane == 0) tile_kept[tile0 + t] = c;
+    }
 }
 
 __device__ __forceinline__ void store_kept(uint8_t* __restrict__ dst, uint4 v, uint32_t m)
@@ -86,26 +96,35 @@ __global__ __launch_bounds__(GAPB) void k_gap_scatter(const uint8_t* __restrict_
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t ntile = (total + GTILE - 1) / GTILE;
-    const uint64_t tile = (uint64_t)blockIdx.x * (GAPB / 64) + (threadIdx.x >> 6);
-    if (tile >= ntile) return;
-    const uint64_t o = tile * GTILE + 16ull * lane;
-    uint4 v = make_uint4(0, 0, 0, 0), q = make_uint4(0, 0, 0, 0);
-    uint32_t m = 0;
-    if (o < total) {
-        v = ld16(seq + o);
-        if (qual) q = ld16(qual + o);
-        m = keep_mask(v, o, total, s_gap);
+    const uint64_t tile0 = ((uint64_t)blockIdx.x * (GAPB / 64) + (threadIdx.x >> 6)) * GTPW;
+    if (tile0 >= ntile) return;
+    uint4 V[GTPW], Q[GTPW];
+#pragma unroll
+    for (int t = 0; t < GTPW; t++) {                      // all loads before the first lookup
+        const uint64_t o = (tile0 + t) * GTILE + 16ull * lane;
+        V[t] = Q[t] = make_uint4(0, 0, 0, 0);
+        if (o < total) {
+            V[t] = ld16(seq + o);
+            if (qual) Q[t] = ld16(qual + o);
+        }
     }
-    const uint32_t c = (uint32_t)__builtin_popcount(m);
-    uint32_t inc = c;                                   // inclusive prefix over the lanes
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t t = __shfl_up(inc, d);
-        if ((int)lane >= d) inc += t;
+#pragma unroll
+    for (int t = 0; t < GTPW; t++) {
+        const uint64_t tile = tile0 + t;
+        if (tile >= ntile) break;                        // wave-uniform
+        const uint64_t o = tile * GTILE + 16ull * lane;
+        const uint32_t m = o < total ? keep_mask(V[t], o, total, s_gap) : 0u;
+        const uint32_t c = (uint32_t)__builtin_popcount(m);
+        uint32_t inc = c;                               // inclusive prefix over the lanes
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t u = __shfl_up(inc, d);
+            if ((int)lane >= d) inc += u;
+        }
+        if (m == 0) continue;
+        const uint64_t dst = tile_base[tile] + (inc - c);
+        store_kept(out_seq + dst, V[t], m);
+        if (qual) store_kept(out_qual + dst, Q[t], m);
     }
-    if (m == 0) return;
-    const uint64_t dst = tile_base[tile] + (inc - c);
-    store_kept(out_seq + dst, v, m);
-    if (qual) store_kept(out_qual + dst, q, m);
 }
 
 // out_offs[nrec] = total of the kept counts; the result for the caller
@@ -156,7 +175,7 @@ hipError_t launch_remove_gaps(const LaunchCfg& cfg, const uint8_t* seq, const ui
     e = launch_scan64(counts, nrec, out_offs, part, totals, s);
     if (e != hipSuccess) return e;
     if (ntile) {
-        const uint64_t g = (ntile + GAPB / 64 - 1) / (GAPB / 64);
+        const uint64_t g = (ntile + (GAPB / 64) * GTPW - 1) / ((GAPB / 64) * GTPW);
         if (g > 0x7fffffffull) return hipErrorInvalidValue;
         hipLaunchKernelGGL(k_gap_tile_count, dim3((uint32_t)g), dim3(GAPB), 0, s, seq, total, is_gap, tile_kept);
         e = launch_scan64(tile_kept, ntile, tile_base, part, totals + 1, s);
