@@ -35,6 +35,17 @@ __device__ __forceinline__ uint64_t find_record(const uint64_t* __restrict__ off
     return lo;
 }
 
+// Hand-over of LDS contents between the lanes of ONE wavefront: what any lane wrote before is
+// visible to every lane after.  The hardware needs nothing for this (a wavefront's LDS operations
+// complete in program order), so no instruction is emitted; the fences at wavefront scope tell the
+// compiler not to move LDS accesses across this point, the barrier keeps the lanes' code together.
+__device__ __forceinline__ void wave_lds_handover()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ uint4 ldu16(const uint8_t* p)     // any byte address
 {
     uint4 v;

@@ -234,30 +234,65 @@ __device__ __forceinline__ uint32_t wave_max32(uint32_t v)
 
 // One 16-byte piece (bytes [p, p + 16) of a field of L bytes, p < L) to its place: plain, or with a '\n' after
 // every `width` bytes but the last line (the piece that holds the base before a break writes the break).
-// The end of a field goes as its last 16 bytes once more (same values); fields under 16 bytes byte by byte.
+// The end of a field goes as its last 16 bytes once more (same values); what fits neither way byte by byte.
+// In two halves, so that a caller can issue the loads of several pieces before the first store: the plan
+// (a pure function of L, p and the width), the loads it asks for, and the stores.
+struct PiecePlan {
+    uint32_t n16;                    // 16-byte copies: 0, 1 or 2
+    uint32_t so0, do0, so1, do1;     // their offsets in the field and in its place
+    uint32_t last, l0;               // last byte of the piece, line of its first byte
+    bool bytewise;                   // bytes [p, last] one by one
+};
+
+__device__ __forceinline__ PiecePlan plan_piece(uint32_t L, uint32_t p, bool wrapped, const Div32& div)
+{
+    PiecePlan pl{0, 0, 0, 0, 0, 0, 0, false};
+    pl.last = p + 16 <= L ? p + 15 : L - 1;
+    if (!wrapped) {
+        if (p + 16 <= L) { pl.n16 = 1; pl.so0 = pl.do0 = p; }
+        else if (L >= 16) { pl.n16 = 1; pl.so0 = pl.do0 = L - 16; }
+        else pl.bytewise = true;
+        return pl;
+    }
+    const uint32_t width = div.width;
+    const uint32_t l0 = div(p), l1 = div(pl.last);
+    pl.l0 = l0;
+    if (l0 == l1 && p + 16 <= L) {
+        pl.n16 = 1; pl.so0 = p; pl.do0 = p + l0;
+    } else if (l0 == l1 && L >= 16 && div(L - 16) == l0) {            // the end of the field, within one line
+        pl.n16 = 1; pl.so0 = L - 16; pl.do0 = L - 16 + l0;
+    } else if (l1 == l0 + 1 && width >= 16 && (l0 + 1) * width >= 16 && (l0 + 1) * width + 16 <= L) {
+        const uint32_t b = (l0 + 1) * width;          // first base of the next line: the 16 bytes that end the line and
+        pl.n16 = 2;                                   // the 16 that start the next one (overlaps carry the same values)
+        pl.so0 = b - 16; pl.do0 = b - 16 + l0;
+        pl.so1 = b; pl.do1 = b + l1;
+    } else {
+        pl.bytewise = true;
+    }
+    return pl;
+}
+
+__device__ __forceinline__ void store_piece(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, uint32_t L, uint32_t p,
+                                            bool wrapped, const Div32& div, const PiecePlan& pl, uint4 v0, uint4 v1)
+{
+    if (pl.n16 >= 1) __builtin_memcpy(dst + pl.do0, &v0, 16);
+    if (pl.n16 == 2) __builtin_memcpy(dst + pl.do1, &v1, 16);
+    if (!wrapped) {
+        if (pl.bytewise) for (uint32_t k = p; k < L; k++) dst[k] = src[k];
+        return;
+    }
+    if (pl.bytewise) for (uint32_t k = p; k <= pl.last; k++) dst[k + div(k)] = src[k];
+    const uint32_t width = div.width, breaks = div(L - 1);
+    for (uint32_t b = pl.l0 + 1; b <= breaks && b * width - 1 <= pl.last; b++) dst[b * width + b - 1] = '\n';
+}
+
 __device__ __forceinline__ void copy_piece(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, uint32_t L, uint32_t p,
                                            bool wrapped, const Div32& div)
 {
-    if (!wrapped) {
-        if (p + 16 <= L) copy16(dst + p, src + p);
-        else if (L >= 16) copy16(dst + L - 16, src + L - 16);
-        else for (uint32_t k = p; k < L; k++) dst[k] = src[k];
-        return;
-    }
-    const uint32_t width = div.width;
-    const uint32_t last = p + 16 <= L ? p + 15 : L - 1;
-    const uint32_t l0 = div(p), l1 = div(last);
-    if (l0 == l1 && p + 16 <= L) {
-        copy16(dst + p + l0, src + p);
-    } else if (l1 == l0 + 1 && width >= 16 && (l0 + 1) * width >= 16 && (l0 + 1) * width + 16 <= L) {
-        const uint32_t b = (l0 + 1) * width;          // first base of the next line: the 16 bytes that end the line and
-        copy16(dst + b - 16 + l0, src + b - 16);      // the 16 that start the next one (overlaps carry the same values)
-        copy16(dst + b + l1, src + b);
-    } else {
-        for (uint32_t k = p; k <= last; k++) dst[k + div(k)] = src[k];
-    }
-    const uint32_t breaks = div(L - 1);
-    for (uint32_t b = l0 + 1; b <= breaks && b * width - 1 <= last; b++) dst[b * width + b - 1] = '\n';
+    const PiecePlan pl = plan_piece(L, p, wrapped, div);
+    const uint4 v0 = pl.n16 >= 1 ? ldu16(src + pl.so0) : make_uint4(0, 0, 0, 0);
+    const uint4 v1 = pl.n16 == 2 ? ldu16(src + pl.so1) : make_uint4(0, 0, 0, 0);
+    store_piece(dst, src, L, p, wrapped, div, pl, v0, v1);
 }
 
 // The text of the n records of a step (lane i holds record i: op = where its text starts in the stage, sz = its
@@ -303,28 +338,49 @@ __device__ __forceinline__ void write_step_flat(const FormatSeqArgs& a, uint8_t*
     const uint64_t s0 = from_lane64(s, 0);               // sequences of a step lie within 4 GiB of each other
     const uint32_t s_rel = (uint32_t)(s - s0);
     // field by field, so that the lanes of one instruction read one kind of source: slot q = lane + 64 k of a
-    // field with PF slots per record is piece q mod PF of record q / PF
+    // field with PF slots per record is piece q mod PF of record q / PF.  PU rounds of slots at a time, the
+    // loads of all of them ahead of the first write to the stage.
+    constexpr int PU = 3;
 #pragma unroll 1
     for (int f = 0; f < 3; f++) {
         const uint32_t PF = f == 0 ? PN : (f == 1 ? PS : PQ);
         if (PF == 0) continue;
         const Div32 by_pf(PF);
         const uint32_t nslots = n * PF;
-        for (uint32_t q0 = 0; q0 < nslots; q0 += 64) {        // every lane takes part in the cross-lane reads
-            const uint32_t q = q0 + lane < nslots ? q0 + lane : nslots - 1;
-            const uint32_t r = by_pf(q), k = q - r * PF;
-            const uint32_t op_r = (uint32_t)__shfl((int)op, (int)r), len_r = (uint32_t)__shfl((int)len, (int)r);
-            const uint32_t nl_r = (uint32_t)__shfl((int)nl, (int)r);
-            uint32_t o_name, o_seq, o_plus, o_qual, w;
-            layout(nl_r, len_r, o_name, o_seq, o_plus, o_qual, w);
-            uint8_t* o = stage + op_r;
-            if (f == 0) {
-                const uint64_t name_r = from_lane64(name, r);
-                if (q0 + lane < nslots && 16 * k < nl_r) copy_piece(o + o_name, a.text + name_r, nl_r, 16 * k, false, div);
-            } else {
+        const bool wrap_f = f != 0 && wrapped;
+        for (uint32_t q0 = 0; q0 < nslots; q0 += 64 * PU) {   // every lane takes part in the cross-lane reads
+            uint4 v0[PU], v1[PU];
+            const uint8_t* src[PU];
+            uint32_t at[PU], L[PU], P[PU];
+            bool act[PU];
+#pragma unroll
+            for (int u = 0; u < PU; u++) {
+                const uint32_t qq = q0 + 64 * u + lane;
+                const uint32_t q = qq < nslots ? qq : nslots - 1;
+                const uint32_t r = by_pf(q), k = q - r * PF;
+                const uint32_t op_r = (uint32_t)__shfl((int)op, (int)r), len_r = (uint32_t)__shfl((int)len, (int)r);
+                const uint32_t nl_r = (uint32_t)__shfl((int)nl, (int)r);
                 const uint32_t srel_r = (uint32_t)__shfl((int)s_rel, (int)r);
-                if (q0 + lane < nslots && 16 * k < len_r)
-                    copy_piece(o + (f == 1 ? o_seq : o_qual), (f == 1 ? a.seq : a.qual) + s0 + srel_r, len_r, 16 * k, wrapped, div);
+                const uint64_t name_r = f == 0 ? from_lane64(name, r) : 0;
+                uint32_t o_name, o_seq, o_plus, o_qual, w;
+                layout(nl_r, len_r, o_name, o_seq, o_plus, o_qual, w);
+                L[u] = f == 0 ? nl_r : len_r;
+                P[u] = 16 * k;
+                at[u] = op_r + (f == 0 ? o_name : (f == 1 ? o_seq : o_qual));
+                src[u] = f == 0 ? a.text + name_r : (f == 1 ? a.seq : a.qual) + s0 + srel_r;
+                act[u] = qq < nslots && P[u] < L[u];
+                v0[u] = v1[u] = make_uint4(0, 0, 0, 0);
+                if (act[u]) {
+                    const PiecePlan pl = plan_piece(L[u], P[u], wrap_f, div);
+                    if (pl.n16 >= 1) v0[u] = ldu16(src[u] + pl.so0);
+                    if (pl.n16 == 2) v1[u] = ldu16(src[u] + pl.so1);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < PU; u++) {
+                if (!act[u]) continue;
+                const PiecePlan pl = plan_piece(L[u], P[u], wrap_f, div);
+                store_piece(stage + at[u], src[u], L[u], P[u], wrap_f, div, pl, v0[u], v1[u]);
             }
         }
     }
@@ -398,14 +454,14 @@ __global__ __launch_bounds__(FB) void k_fmt_write(const FormatSeqArgs a, const u
         const uint32_t t_size = (uint32_t)(t_end - t_pos);
         if (p1 == p0) continue;
         write_step_flat(a, stage, lane, n, div, (uint32_t)(t_pos - a0), t_size, t_len, t_nl, t_s, t_name);
-        __builtin_amdgcn_wave_barrier();
+        wave_lds_handover();
         const uint32_t nbytes = (uint32_t)(p1 - a0), head = (uint32_t)(p0 - a0);
         const uint32_t c_lo = head ? 16u : 0u, c_hi = nbytes & ~15u;
         for (uint32_t c = lane * 16; c < c_hi; c += 1024)
             if (c >= c_lo) *reinterpret_cast<uint4*>(out + a0 + c) = *reinterpret_cast<const uint4*>(stage + c);
         if (head && lane >= head && lane < 16 && lane < nbytes) out[a0 + lane] = stage[lane];
         if (c_hi < nbytes && (c_hi != 0 || !head) && lane < nbytes - c_hi) out[a0 + c_hi + lane] = stage[c_hi + lane];
-        __builtin_amdgcn_wave_barrier();
+        wave_lds_handover();
     }
 }
 
@@ -738,14 +794,14 @@ __global__ __launch_bounds__(FB) void k_tab_rows(const FormatTabArgs a, const ui
                 }
             }
         }
-        __builtin_amdgcn_wave_barrier();
+        wave_lds_handover();
         const uint32_t nbytes = (uint32_t)(p1 - a0), head = (uint32_t)(p0 - a0);
         const uint32_t c_lo = head ? 16u : 0u, c_hi = nbytes & ~15u;
         for (uint32_t c = lane * 16; c < c_hi; c += 1024)
             if (c >= c_lo) *reinterpret_cast<uint4*>(out + a0 + c) = *reinterpret_cast<const uint4*>(stage + c);
         if (head && lane >= head && lane < 16 && lane < nbytes) out[a0 + lane] = stage[lane];
         if (c_hi < nbytes && (c_hi != 0 || !head) && lane < nbytes - c_hi) out[a0 + c_hi + lane] = stage[c_hi + lane];
-        __builtin_amdgcn_wave_barrier();
+        wave_lds_handover();
     }
 }
 

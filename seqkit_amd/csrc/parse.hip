@@ -28,6 +28,7 @@
 #include <stdint.h>
 
 #include "kernels.h"
+#include "device_util.h"
 
 namespace skh {
 
@@ -97,14 +98,36 @@ __device__ __forceinline__ uint32_t nl_mask_at(const uint8_t* __restrict__ text,
     return m;
 }
 
+// number of '\n' among the 16 bytes: the zero-byte detector of nl_mask16 without putting the mask together
+__device__ __forceinline__ uint32_t nl_count16(uint4 v)
+{
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint32_t other = 0;                                     // bytes that are not '\n'
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        const uint32_t x = w[d] ^ 0x0a0a0a0au;
+        other += __builtin_popcount((((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u);
+    }
+    return 16u - other;
+}
+
 __global__ __launch_bounds__(PB) void k_nl_count(const uint8_t* __restrict__ text, uint64_t n,
                                                  uint32_t* __restrict__ tile_count)
 {
     __shared__ uint32_t s_wave[PB / 64];
     uint32_t c = 0;
+    const uint64_t t0 = (uint64_t)blockIdx.x * TILE;
+    if (t0 + TILE <= n) {                                   // a whole tile: all loads first, no masks
+        uint4 v[NLU];
 #pragma unroll
-    for (int u = 0; u < NLU; u++)
-        c += __builtin_popcount(nl_mask_at(text, n, (uint64_t)blockIdx.x * TILE + (uint64_t)(u * PB + threadIdx.x) * 16));
+        for (int u = 0; u < NLU; u++) v[u] = *reinterpret_cast<const uint4*>(text + t0 + (uint64_t)(u * PB + threadIdx.x) * 16);
+#pragma unroll
+        for (int u = 0; u < NLU; u++) c += nl_count16(v[u]);
+    } else {
+#pragma unroll
+        for (int u = 0; u < NLU; u++)
+            c += __builtin_popcount(nl_mask_at(text, n, t0 + (uint64_t)(u * PB + threadIdx.x) * 16));
+    }
     uint32_t total;
     block_excl_scan(c, &total, s_wave);
     if (threadIdx.x == 0) tile_count[blockIdx.x] = total;
@@ -151,31 +174,73 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(const uint32_t* __restrict_
     if (threadIdx.x == 0) *n_out = carry;
 }
 
+// The newlines of a tile, in text order (chunk row u, then thread), behind the tile's base.  The four
+// chunk loads of a thread go out together; the four row-wise counts are scanned at once as 16-bit fields
+// of one 64-bit word (a row holds at most PB * 16 = 4096 newlines), so the tile costs one barrier.
 __global__ __launch_bounds__(PB) void k_nl_scatter(const uint8_t* __restrict__ text, uint64_t n,
                                                    const uint64_t* __restrict__ tile_base,
                                                    uint64_t* __restrict__ nlpos, uint64_t max_lines)
 {
-    __shared__ uint32_t s_wave[PB / 64];
+    static_assert(NLU == 4 && PB * 16 < 65536, "four 16-bit fields");
+    __shared__ uint64_t s_wave[PB / 64];
+    __shared__ uint4 s_text[TILE / 16];                   // the tile: the bytes next to a newline are looked up here
+    const uint8_t* s_byte = reinterpret_cast<const uint8_t*>(s_text);
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t t0 = (uint64_t)blockIdx.x * TILE;
     uint64_t run = tile_base[blockIdx.x];
+    uint32_t m[NLU];
+    {
+        uint4 v[NLU];
 #pragma unroll
-    for (int u = 0; u < NLU; u++) {                      // chunks in text order: u-major, then thread
-        const uint64_t o = (uint64_t)blockIdx.x * TILE + (uint64_t)(u * PB + threadIdx.x) * 16;
-        uint32_t m = nl_mask_at(text, n, o);
-        uint32_t total;
-        const uint32_t ex = block_excl_scan(__builtin_popcount(m), &total, s_wave);
-        uint64_t k = run + ex;
-        while (m) {
-            const uint32_t bit = __builtin_ctz(m);
-            m &= m - 1;
+        for (int u = 0; u < NLU; u++) {
+            const uint64_t o = t0 + (uint64_t)(u * PB + threadIdx.x) * 16;
+            v[u] = o < n ? *reinterpret_cast<const uint4*>(text + o) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < NLU; u++) {
+            const uint64_t o = t0 + (uint64_t)(u * PB + threadIdx.x) * 16;
+            s_text[u * PB + threadIdx.x] = v[u];
+            m[u] = nl_mask16(v[u]);
+            if (o + 16 > n) m[u] &= o < n ? (1u << (n - o)) - 1u : 0u;
+        }
+    }
+    uint64_t mine = 0;
+#pragma unroll
+    for (int u = 0; u < NLU; u++) mine |= (uint64_t)__builtin_popcount(m[u]) << (16 * u);
+    uint64_t inc = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint64_t t = ((uint64_t)(uint32_t)__shfl_up((int)(uint32_t)(inc >> 32), d) << 32) | (uint32_t)__shfl_up((int)(uint32_t)inc, d);
+        if ((int)lane >= d) inc += t;
+    }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    uint64_t before = 0, all = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < PB / 64; w++) {
+        const uint64_t x = s_wave[w];
+        if (w < wave) before += x;
+        all += x;
+    }
+    const uint64_t ex = before + inc - mine;             // per row: newlines of the row before this thread's chunk
+#pragma unroll
+    for (int u = 0; u < NLU; u++) {
+        const uint64_t o = t0 + (uint64_t)(u * PB + threadIdx.x) * 16;
+        uint64_t k = run + ((ex >> (16 * u)) & 0xffffu);
+        uint32_t mm = m[u];
+        while (mm) {
+            const uint32_t bit = __builtin_ctz(mm);
+            mm &= mm - 1;
             const uint64_t p = o + bit;
             if (k < max_lines) {
-                const uint64_t cr = (p > 0 && text[p - 1] == '\r') ? NL_CR : 0;
-                const uint64_t next = p + 1 < n ? text[p + 1] : 0;
-                nlpos[k] = p | (next << NL_NEXT_SHIFT) | cr;
+                const uint32_t q = (uint32_t)(p - t0);     // the neighbours outside the tile come from memory
+                const uint32_t prev = q > 0 ? s_byte[q - 1] : (p > 0 ? text[p - 1] : 0);
+                const uint32_t next = p + 1 >= n ? 0 : (q + 1 < TILE ? s_byte[q + 1] : text[p + 1]);
+                nlpos[k] = p | ((uint64_t)next << NL_NEXT_SHIFT) | (prev == '\r' ? NL_CR : 0);
             }
             k++;
         }
-        run += total;
+        run += (all >> (16 * u)) & 0xffffu;
     }
 }
 
@@ -213,16 +278,14 @@ __global__ void k_parse_init(ParseState* st, uint64_t n, int final, const uint8_
 }
 
 // Line i: its start, its length without the trailing '\r's, and its first byte (0 if empty).
-__device__ __forceinline__ void line_span(const uint8_t* __restrict__ text, uint64_t n,
-                                          const uint64_t* __restrict__ nlpos, uint64_t n_nl, uint64_t i,
-                                          uint64_t& ls, uint32_t& len, uint8_t& first)
+// `before` and `e` are the newline entries i - 1 and i (read by the caller; unused where there is none).
+__device__ __forceinline__ void line_span(const uint8_t* __restrict__ text, uint64_t n, uint64_t before, uint64_t e,
+                                          uint64_t n_nl, uint64_t i, uint64_t& ls, uint32_t& len, uint8_t& first)
 {
-    const uint64_t before = i ? nlpos[i - 1] : 0;
     ls = i ? (before & NL_POS) + 1 : 0;
     uint64_t le;
     bool cr;
     if (i < n_nl) {
-        const uint64_t e = nlpos[i];
         le = e & NL_POS;
         cr = (e & NL_CR) != 0;
     } else {                                             // the unterminated last line
@@ -245,28 +308,42 @@ __global__ __launch_bounds__(PB) void k_line_table(const uint8_t* __restrict__ t
     // per thread, then per wavefront, then one atomic each: the flags of the whole text
     unsigned long long err = ~0ull, blank_head = ~0ull, last = 0;
     bool any = false;
-    for (uint64_t i = (uint64_t)blockIdx.x * PB + threadIdx.x; i < nlines; i += (uint64_t)gridDim.x * PB) {
-        uint64_t ls; uint32_t len; uint8_t c;
-        line_span(text, n, nlpos, n_nl, i, ls, len, c);
-        bool head, bad = false;
-        if (!FASTQ) {
-            head = c == '>';
-        } else {
-            const uint32_t role = (uint32_t)(i & 3);
-            head = role == 0;
-            if (role == 0) {
-                if (len == 0) blank_head = i < blank_head ? i : blank_head;
-                else bad = c != '@';
-            } else if (role == 2) {
-                bad = c != '+';
-            }                                            // role 3 (equal lengths) is checked by k_line_partials
+    constexpr int LU = 4;                                 // lines per thread in flight
+    const uint64_t stride = (uint64_t)gridDim.x * PB;
+    for (uint64_t i0 = (uint64_t)blockIdx.x * PB + threadIdx.x; i0 < nlines; i0 += LU * stride) {
+        uint64_t e_before[LU], e_here[LU];
+#pragma unroll
+        for (int k = 0; k < LU; k++) {
+            const uint64_t i = i0 + k * stride;
+            e_before[k] = (i != 0 && i < nlines) ? nlpos[i - 1] : 0;
+            e_here[k] = i < n_nl ? nlpos[i] : 0;
         }
-        if (len) { last = i; any = true; }            // i grows within a thread
-        if (len > LONG_LINE) atomicAdd(&st->n_long, 1u);
-        if (bad && i < err) err = i;
-        line_start[i] = ls;
-        line_len[i] = len;
-        line_head[i] = head ? 1 : 0;
+#pragma unroll
+        for (int k = 0; k < LU; k++) {
+            const uint64_t i = i0 + k * stride;
+            if (i >= nlines) break;
+            uint64_t ls; uint32_t len; uint8_t c;
+            line_span(text, n, e_before[k], e_here[k], n_nl, i, ls, len, c);
+            bool head, bad = false;
+            if (!FASTQ) {
+                head = c == '>';
+            } else {
+                const uint32_t role = (uint32_t)(i & 3);
+                head = role == 0;
+                if (role == 0) {
+                    if (len == 0) blank_head = i < blank_head ? i : blank_head;
+                    else bad = c != '@';
+                } else if (role == 2) {
+                    bad = c != '+';
+                }                                            // role 3 (equal lengths) is checked by k_line_partials
+            }
+            if (len) { last = i; any = true; }            // i grows within a thread
+            if (len > LONG_LINE) atomicAdd(&st->n_long, 1u);
+            if (bad && i < err) err = i;
+            line_start[i] = ls;
+            line_len[i] = len;
+            line_head[i] = head ? 1 : 0;
+        }
     }
     for (int d = 1; d < 64; d <<= 1) {
         const unsigned long long e2 = __shfl_xor(err, d), b2 = __shfl_xor(blank_head, d), l2 = __shfl_xor(last, d);
@@ -313,6 +390,34 @@ __device__ __forceinline__ LineSum line_item(const uint32_t* __restrict__ line_l
     return v;
 }
 
+// The SCAN_ITEMS consecutive lines of a thread, from `base` (a multiple of SCAN_ITEMS): vector loads when
+// all of them exist, one by one at the end of the table.  len[] receives the plain lengths.
+template <bool FASTQ>
+__device__ __forceinline__ void line_items(const uint32_t* __restrict__ line_len, const uint8_t* __restrict__ line_head,
+                                           uint64_t base, uint64_t nlines, LineSum* v, uint32_t* len)
+{
+    static_assert(SCAN_ITEMS == 8, "two 16-byte loads of lengths, one 8-byte load of flags");
+    if (base + SCAN_ITEMS <= nlines) {
+        const uint4 l0 = *reinterpret_cast<const uint4*>(line_len + base), l1 = *reinterpret_cast<const uint4*>(line_len + base + 4);
+        const uint2 hd = *reinterpret_cast<const uint2*>(line_head + base);
+        const uint32_t l[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const bool head = (((k < 4 ? hd.x : hd.y) >> (8 * (k & 3))) & 0xffu) != 0;
+            len[k] = l[k];
+            v[k].heads = head ? 1u : 0u;
+            if (FASTQ) v[k].bytes = (k & 3) == 1 ? l[k] : 0;       // base is a multiple of 4
+            else v[k].bytes = head ? 0 : l[k];
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; k++) {
+            v[k] = line_item<FASTQ>(line_len, line_head, base + k, nlines);
+            len[k] = base + k < nlines ? line_len[base + k] : 0;
+        }
+    }
+}
+
 template <bool FASTQ>
 __global__ __launch_bounds__(PB) void k_line_partials(const uint32_t* __restrict__ line_len,
                                                       const uint8_t* __restrict__ line_head, ParseState* st,
@@ -323,12 +428,14 @@ __global__ __launch_bounds__(PB) void k_line_partials(const uint32_t* __restrict
     const uint64_t nlines = st->nlines;
     const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
     uint64_t b = 0; uint32_t h = 0;
+    LineSum v[SCAN_ITEMS];
+    uint32_t len[SCAN_ITEMS];
+    line_items<FASTQ>(line_len, line_head, base, nlines, v, len);
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; k++) {
-        const LineSum v = line_item<FASTQ>(line_len, line_head, base + k, nlines);
-        b += v.bytes; h += v.heads;
-        // FASTQ: a quality line must be as long as its sequence line (two lines up)
-        if (FASTQ && base + k < nlines && ((base + k) & 3) == 3 && line_len[base + k] != line_len[base + k - 2])
+        b += v[k].bytes; h += v[k].heads;
+        // FASTQ: a quality line must be as long as its sequence line (two lines up, held by the same thread)
+        if (FASTQ && (k & 3) == 3 && base + k < nlines && len[k] != len[k - 2])
             atomicMin(&st->err_line, (unsigned long long)(base + k));
     }
     for (int d = 1; d < 64; d <<= 1) { b += __shfl_xor(b, d); h += __shfl_xor(h, d); }
@@ -341,31 +448,40 @@ __global__ __launch_bounds__(PB) void k_line_partials(const uint32_t* __restrict
     }
 }
 
+// Exclusive scan of the workgroup sums, in place, by one workgroup: rounds of 1024 consecutive entries
+// (one per thread, the next round's entry loaded before this round is scanned), a shuffle scan per
+// wavefront, the 16 wavefront totals through LDS, the running total carried in registers.
 __global__ __launch_bounds__(1024) void k_scan_partials(LineSum* __restrict__ part, uint64_t npart, ParseState* st)
 {
-    __shared__ uint64_t s_b[1024];
-    __shared__ uint32_t s_h[1024];
-    const uint64_t per = (npart + 1023) / 1024;
-    const uint64_t a = threadIdx.x * per, b = a + per < npart ? a + per : npart;
-    uint64_t sb = 0; uint32_t sh = 0;
-    for (uint64_t i = a; i < b; i++) { sb += part[i].bytes; sh += part[i].heads; }
-    s_b[threadIdx.x] = sb; s_h[threadIdx.x] = sh;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint64_t rb = 0; uint32_t rh = 0;
-        for (int i = 0; i < 1024; i++) {
-            const uint64_t tb = s_b[i]; const uint32_t th = s_h[i];
-            s_b[i] = rb; s_h[i] = rh; rb += tb; rh += th;
+    __shared__ uint64_t s_b[16];
+    __shared__ uint32_t s_h[16];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint64_t cb = 0; uint32_t ch = 0;                     // sum of everything before this round
+    LineSum nxt{0, 0};
+    if (threadIdx.x < npart) nxt = part[threadIdx.x];
+    for (uint64_t base = 0; base < npart; base += 1024) {
+        const uint64_t i = base + threadIdx.x;
+        const LineSum v = nxt;
+        nxt = LineSum{0, 0};
+        if (i + 1024 < npart) nxt = part[i + 1024];
+        uint64_t ib = v.bytes; uint32_t ih = v.heads;
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint64_t tb = __shfl_up(ib, d); const uint32_t th = __shfl_up(ih, d);
+            if ((int)lane >= d) { ib += tb; ih += th; }
         }
-        st->total.bytes = rb; st->total.heads = rh;
+        if (lane == 63) { s_b[wave] = ib; s_h[wave] = ih; }
+        __syncthreads();
+        uint64_t rb = cb + ib - v.bytes; uint32_t rh = ch + ih - v.heads;
+#pragma unroll
+        for (uint32_t w = 0; w < 16; w++) {
+            const uint64_t tb = s_b[w]; const uint32_t th = s_h[w];
+            if (w < wave) { rb += tb; rh += th; }
+            cb += tb; ch += th;
+        }
+        if (i < npart) { part[i].bytes = rb; part[i].heads = rh; }
+        __syncthreads();                                  // the totals are rewritten in the next round
     }
-    __syncthreads();
-    uint64_t rb = s_b[threadIdx.x]; uint32_t rh = s_h[threadIdx.x];
-    for (uint64_t i = a; i < b; i++) {
-        const LineSum t = part[i];
-        part[i].bytes = rb; part[i].heads = rh;
-        rb += t.bytes; rh += t.heads;
-    }
+    if (threadIdx.x == 0) { st->total.bytes = cb; st->total.heads = ch; }
 }
 
 template <bool FASTQ>
@@ -379,12 +495,11 @@ __global__ __launch_bounds__(PB) void k_line_scan(const uint32_t* __restrict__ l
     const uint64_t nlines = st->nlines;
     const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
     LineSum v[SCAN_ITEMS];
+    uint32_t len[SCAN_ITEMS];
     uint64_t b = 0; uint32_t h = 0;
+    line_items<FASTQ>(line_len, line_head, base, nlines, v, len);
 #pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; k++) {
-        v[k] = line_item<FASTQ>(line_len, line_head, base + k, nlines);
-        b += v[k].bytes; h += v[k].heads;
-    }
+    for (int k = 0; k < SCAN_ITEMS; k++) { b += v[k].bytes; h += v[k].heads; }
     // inclusive scan of the per-thread sums across the wavefront, then across wavefronts
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint64_t ib = b; uint32_t ih = h;
@@ -396,6 +511,19 @@ __global__ __launch_bounds__(PB) void k_line_scan(const uint32_t* __restrict__ l
     __syncthreads();
     uint64_t rb = part[blockIdx.x].bytes + ib - b; uint32_t rh = part[blockIdx.x].heads + ih - h;
     for (uint32_t w = 0; w < wave; w++) { rb += s_b[w]; rh += s_h[w]; }
+    if (base + SCAN_ITEMS <= nlines) {                    // 16-byte stores
+        uint64_t d[SCAN_ITEMS]; uint32_t r[SCAN_ITEMS];
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; k++) { d[k] = rb; r[k] = rh; rb += v[k].bytes; rh += v[k].heads; }
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; k += 2)
+            *reinterpret_cast<uint4*>(line_dst + base + k) =
+                make_uint4((uint32_t)d[k], (uint32_t)(d[k] >> 32), (uint32_t)d[k + 1], (uint32_t)(d[k + 1] >> 32));
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; k += 4)
+            *reinterpret_cast<uint4*>(line_rank + base + k) = make_uint4(r[k], r[k + 1], r[k + 2], r[k + 3]);
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; k++) {
         if (base + k < nlines) { line_dst[base + k] = rb; line_rank[base + k] = rh; }
@@ -601,28 +729,37 @@ __global__ __launch_bounds__(PB) void k_parse_copy(const ParseState* st, uint64_
         if (PF != 0) {
             const uint32_t nslots = (last + 1) * PF;
             const uint32_t magic = PF > 1 ? (uint32_t)((0x100000000ull + PF - 1) / PF) : 0u;   // q / PF for q < 2^16
-            for (uint32_t q0 = 0; q0 < nslots; q0 += 64) {            // every lane takes part in the cross-lane reads
-                const uint32_t q = q0 + lane < nslots ? q0 + lane : nslots - 1;
-                const uint32_t r = PF > 1 ? __umulhi(q, magic) : q, k = q - r * PF;
-                const uint32_t len = (uint32_t)__shfl((int)t_len, (int)r), dr = (uint32_t)__shfl((int)d_rel, (int)r);
-                const uint32_t sr = (uint32_t)__shfl((int)st_rel, (int)r);
-                const uint32_t p = 16 * k;
-                if (q0 + lane >= nslots || p >= len) continue;
-                uint8_t* out = s_stage[wave][FASTQ ? (r & 1u) : 0u] + dr;
-                const uint8_t* src = text + start0 + sr;
-                uint4 v;
-                if (p + 16 <= len) {
-                    __builtin_memcpy(&v, src + p, 16);
-                    __builtin_memcpy(out + p, &v, 16);
-                } else if (len >= 16) {                               // the last 16 bytes again: same values, no byte loop
-                    __builtin_memcpy(&v, src + len - 16, 16);
-                    __builtin_memcpy(out + len - 16, &v, 16);
-                } else {
-                    for (uint32_t b = p; b < len; b++) out[b] = src[b];
+            // PU rounds of slots at a time, the loads of all of them ahead of the first LDS write
+            constexpr int PU = 4;
+            uint8_t* const stage0 = s_stage[wave][0];
+            for (uint32_t q0 = 0; q0 < nslots; q0 += 64 * PU) {       // every lane takes part in the cross-lane reads
+                uint4 v[PU];
+                uint32_t at[PU];
+                bool act[PU];
+#pragma unroll
+                for (int u = 0; u < PU; u++) {
+                    const uint32_t qq = q0 + 64 * u + lane;
+                    const uint32_t q = qq < nslots ? qq : nslots - 1;
+                    const uint32_t r = PF > 1 ? __umulhi(q, magic) : q, k = q - r * PF;
+                    const uint32_t len = (uint32_t)__shfl((int)t_len, (int)r), dr = (uint32_t)__shfl((int)d_rel, (int)r);
+                    const uint32_t sr = (uint32_t)__shfl((int)st_rel, (int)r);
+                    const uint32_t p = 16 * k;
+                    const bool in = qq < nslots && p < len;
+                    const uint32_t plane = FASTQ ? (r & 1u) * (PC_STAGE + 32) : 0u;
+                    act[u] = in && len >= 16;
+                    const uint32_t off = p + 16 <= len ? p : len - 16;   // a line's last piece: its last 16 bytes again
+                    at[u] = plane + dr + off;
+                    const uint8_t* src = text + start0 + sr;
+                    v[u] = act[u] ? ldu16(src + off) : make_uint4(0, 0, 0, 0);
+                    if (in && len < 16)
+                        for (uint32_t b = 0; b < len; b++) stage0[plane + dr + b] = src[b];
                 }
+#pragma unroll
+                for (int u = 0; u < PU; u++)
+                    if (act[u]) { const uint4 t = v[u]; __builtin_memcpy(stage0 + at[u], &t, 16); }
             }
         }
-        __builtin_amdgcn_wave_barrier();
+        wave_lds_handover();
         const uint32_t nbytes = (uint32_t)(p1 - a0), head = (uint32_t)(p0 - a0);
         const uint32_t c_lo = head ? 16u : 0u, c_hi = nbytes & ~15u;
 #pragma unroll
@@ -634,7 +771,7 @@ __global__ __launch_bounds__(PB) void k_parse_copy(const ParseState* st, uint64_
             if (head && lane >= head && lane < 16 && lane < nbytes) out[a0 + lane] = stage[lane];
             if (c_hi < nbytes && (c_hi != 0 || !head) && lane < nbytes - c_hi) out[a0 + c_hi + lane] = stage[c_hi + lane];
         }
-        __builtin_amdgcn_wave_barrier();
+        wave_lds_handover();
     }
 }
 

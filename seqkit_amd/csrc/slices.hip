@@ -205,12 +205,12 @@ __global__ __launch_bounds__(SB) void k_slice_copy(const uint8_t* __restrict__ i
                     if (have && r_lo == tbase && tcount == SL_T) break;       // SL_T slices do not reach the span's end
                     tbase = r_lo; tcount = 0; rs = 0; have = true;
                 }
-                __builtin_amdgcn_wave_barrier();
+                wave_lds_handover();
                 const uint64_t idx = tbase + tcount + lane;
                 t_oo[tcount + lane] = idx <= n ? oo[idx] : ~0ull;
                 t_src[tcount + lane] = idx < n ? src[idx] : 0;
                 tcount += 64;
-                __builtin_amdgcn_wave_barrier();
+                wave_lds_handover();
                 j = scan();
             }
             if (j < 0) {
@@ -389,14 +389,14 @@ __global__ __launch_bounds__(SB) void k_slice_copy_flat(const uint8_t* __restric
                 }
             }
         }
-        __builtin_amdgcn_wave_barrier();
+        wave_lds_handover();
         const uint32_t nbytes = (uint32_t)(p1 - a0), head = (uint32_t)(p0 - a0);
         const uint32_t c_lo = head ? 16u : 0u, c_hi = nbytes & ~15u;
         for (uint32_t c = lane * 16; c < c_hi; c += 1024)
             if (c >= c_lo) *reinterpret_cast<uint4*>(out + a0 + c) = *reinterpret_cast<const uint4*>(stage + c);
         if (head && lane >= head && lane < 16 && lane < nbytes) out[a0 + lane] = stage[lane];
         if (c_hi < nbytes && (c_hi != 0 || !head) && lane < nbytes - c_hi) out[a0 + c_hi + lane] = stage[c_hi + lane];
-        __builtin_amdgcn_wave_barrier();
+        wave_lds_handover();
     }
 }
 
