@@ -295,6 +295,46 @@ __device__ __forceinline__ void copy_piece(uint8_t* __restrict__ dst, const uint
     store_piece(dst, src, L, p, wrapped, div, pl, v0, v1);
 }
 
+// One field (names, bases or qualities) of the n records of a step copied into the stage, its 16-byte pieces
+// dealt over the 64 lanes: the field gets PF piece slots per record (the most any record of the step needs),
+// slot q = lane + 64 k is piece q mod PF of record q / PF.  field_of(r, L, at, src), called by all lanes
+// together (it reads across lanes), gives the field of record r: its length, its place in the stage and its
+// source.  PU rounds of slots at a time, the loads of all of them ahead of the first write to the stage.
+template <int PU, typename F>
+__device__ __forceinline__ void flat_copy_field(uint8_t* __restrict__ stage, uint32_t lane, uint32_t n, uint32_t PF, bool wrap,
+                                                const Div32& div, F&& field_of)
+{
+    const Div32 by_pf(PF);
+    const uint32_t nslots = n * PF;
+    for (uint32_t q0 = 0; q0 < nslots; q0 += 64 * PU) {
+        uint4 v0[PU], v1[PU];
+        const uint8_t* src[PU];
+        uint32_t at[PU], L[PU], P[PU];
+        bool act[PU];
+#pragma unroll
+        for (int u = 0; u < PU; u++) {
+            const uint32_t qq = q0 + 64 * u + lane;
+            const uint32_t q = qq < nslots ? qq : nslots - 1;
+            const uint32_t r = by_pf(q), k = q - r * PF;
+            field_of(r, L[u], at[u], src[u]);
+            P[u] = 16 * k;
+            act[u] = qq < nslots && P[u] < L[u];
+            v0[u] = v1[u] = make_uint4(0, 0, 0, 0);
+            if (act[u]) {
+                const PiecePlan pl = plan_piece(L[u], P[u], wrap, div);
+                if (pl.n16 >= 1) v0[u] = ldu16(src[u] + pl.so0);
+                if (pl.n16 == 2) v1[u] = ldu16(src[u] + pl.so1);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < PU; u++) {
+            if (!act[u]) continue;
+            const PiecePlan pl = plan_piece(L[u], P[u], wrap, div);
+            store_piece(stage + at[u], src[u], L[u], P[u], wrap, div, pl, v0[u], v1[u]);
+        }
+    }
+}
+
 // The text of the n records of a step (lane i holds record i: op = where its text starts in the stage, sz = its
 // size, 0 for a record that is not printed) put together in the stage.  The separators are written by the
 // record's own lane; the 16-byte pieces of names, bases and qualities of ALL records are dealt over the 64
@@ -337,52 +377,22 @@ __device__ __forceinline__ void write_step_flat(const FormatSeqArgs& a, uint8_t*
     }
     const uint64_t s0 = from_lane64(s, 0);               // sequences of a step lie within 4 GiB of each other
     const uint32_t s_rel = (uint32_t)(s - s0);
-    // field by field, so that the lanes of one instruction read one kind of source: slot q = lane + 64 k of a
-    // field with PF slots per record is piece q mod PF of record q / PF.  PU rounds of slots at a time, the
-    // loads of all of them ahead of the first write to the stage.
-    constexpr int PU = 3;
+    // field by field, so that the lanes of one instruction read one kind of source
 #pragma unroll 1
     for (int f = 0; f < 3; f++) {
         const uint32_t PF = f == 0 ? PN : (f == 1 ? PS : PQ);
         if (PF == 0) continue;
-        const Div32 by_pf(PF);
-        const uint32_t nslots = n * PF;
-        const bool wrap_f = f != 0 && wrapped;
-        for (uint32_t q0 = 0; q0 < nslots; q0 += 64 * PU) {   // every lane takes part in the cross-lane reads
-            uint4 v0[PU], v1[PU];
-            const uint8_t* src[PU];
-            uint32_t at[PU], L[PU], P[PU];
-            bool act[PU];
-#pragma unroll
-            for (int u = 0; u < PU; u++) {
-                const uint32_t qq = q0 + 64 * u + lane;
-                const uint32_t q = qq < nslots ? qq : nslots - 1;
-                const uint32_t r = by_pf(q), k = q - r * PF;
-                const uint32_t op_r = (uint32_t)__shfl((int)op, (int)r), len_r = (uint32_t)__shfl((int)len, (int)r);
-                const uint32_t nl_r = (uint32_t)__shfl((int)nl, (int)r);
-                const uint32_t srel_r = (uint32_t)__shfl((int)s_rel, (int)r);
-                const uint64_t name_r = f == 0 ? from_lane64(name, r) : 0;
-                uint32_t o_name, o_seq, o_plus, o_qual, w;
-                layout(nl_r, len_r, o_name, o_seq, o_plus, o_qual, w);
-                L[u] = f == 0 ? nl_r : len_r;
-                P[u] = 16 * k;
-                at[u] = op_r + (f == 0 ? o_name : (f == 1 ? o_seq : o_qual));
-                src[u] = f == 0 ? a.text + name_r : (f == 1 ? a.seq : a.qual) + s0 + srel_r;
-                act[u] = qq < nslots && P[u] < L[u];
-                v0[u] = v1[u] = make_uint4(0, 0, 0, 0);
-                if (act[u]) {
-                    const PiecePlan pl = plan_piece(L[u], P[u], wrap_f, div);
-                    if (pl.n16 >= 1) v0[u] = ldu16(src[u] + pl.so0);
-                    if (pl.n16 == 2) v1[u] = ldu16(src[u] + pl.so1);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < PU; u++) {
-                if (!act[u]) continue;
-                const PiecePlan pl = plan_piece(L[u], P[u], wrap_f, div);
-                store_piece(stage + at[u], src[u], L[u], P[u], wrap_f, div, pl, v0[u], v1[u]);
-            }
-        }
+        flat_copy_field<3>(stage, lane, n, PF, f != 0 && wrapped, div,
+                           [&](uint32_t r, uint32_t& L, uint32_t& at, const uint8_t*& src) {
+            const uint32_t op_r = (uint32_t)__shfl((int)op, (int)r), len_r = (uint32_t)__shfl((int)len, (int)r);
+            const uint32_t nl_r = (uint32_t)__shfl((int)nl, (int)r), srel_r = (uint32_t)__shfl((int)s_rel, (int)r);
+            const uint64_t name_r = f == 0 ? from_lane64(name, r) : 0;
+            uint32_t o_name, o_seq, o_plus, o_qual, w;
+            layout(nl_r, len_r, o_name, o_seq, o_plus, o_qual, w);
+            L = f == 0 ? nl_r : len_r;
+            at = op_r + (f == 0 ? o_name : (f == 1 ? o_seq : o_qual));
+            src = f == 0 ? a.text + name_r : (f == 1 ? a.seq : a.qual) + s0 + srel_r;
+        });
     }
 }
 
@@ -775,24 +785,14 @@ __global__ __launch_bounds__(FB) void k_tab_rows(const FormatTabArgs a, const ui
             if ((f == 1 && !a.print_seq) || (f == 2 && !a.print_qual)) continue;
             const uint32_t PF = wave_max32(((f == 0 ? f_nl : f_len) + 15) >> 4);
             if (PF == 0) continue;
-            const Div32 by_pf(PF);
-            const uint32_t nslots = n * PF;
-            for (uint32_t q0 = 0; q0 < nslots; q0 += 64) {            // every lane takes part in the cross-lane reads
-                const uint32_t q = q0 + lane < nslots ? q0 + lane : nslots - 1;
-                const uint32_t r = by_pf(q), k = q - r * PF;
+            flat_copy_field<3>(stage, lane, n, PF, false, no_wrap, [&](uint32_t r, uint32_t& L, uint32_t& at, const uint8_t*& src) {
                 const uint32_t op_r = (uint32_t)__shfl((int)op, (int)r), len_r = (uint32_t)__shfl((int)f_len, (int)r);
-                const uint32_t nl_r = (uint32_t)__shfl((int)f_nl, (int)r);
-                uint8_t* o = stage + op_r;
-                if (f == 0) {
-                    const uint64_t name_r = from_lane64(t_name, r);
-                    if (q0 + lane < nslots && 16 * k < nl_r) copy_piece(o, a.text + name_r, nl_r, 16 * k, false, no_wrap);
-                } else {
-                    const uint32_t srel_r = (uint32_t)__shfl((int)s_rel, (int)r);
-                    const uint32_t at = nl_r + 1 + (f == 2 ? (a.print_seq ? len_r : 0u) + 1 : 0u);
-                    if (q0 + lane < nslots && 16 * k < len_r)
-                        copy_piece(o + at, (f == 1 ? a.seq : a.qual) + s0 + srel_r, len_r, 16 * k, false, no_wrap);
-                }
-            }
+                const uint32_t nl_r = (uint32_t)__shfl((int)f_nl, (int)r), srel_r = (uint32_t)__shfl((int)s_rel, (int)r);
+                const uint64_t name_r = f == 0 ? from_lane64(t_name, r) : 0;
+                L = f == 0 ? nl_r : len_r;
+                at = op_r + (f == 0 ? 0u : nl_r + 1 + (f == 2 ? (a.print_seq ? len_r : 0u) + 1 : 0u));
+                src = f == 0 ? a.text + name_r : (f == 1 ? a.seq : a.qual) + s0 + srel_r;
+            });
         }
         wave_lds_handover();
         const uint32_t nbytes = (uint32_t)(p1 - a0), head = (uint32_t)(p0 - a0);

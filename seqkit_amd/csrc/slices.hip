@@ -359,34 +359,44 @@ __global__ __launch_bounds__(SB) void k_slice_copy_flat(const uint8_t* __restric
         for (int d = 1; d < 64; d <<= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)PF, d); PF = t > PF ? t : PF; }
         const uint32_t nslots = cnt * PF;                // PF >= 1: the step has bytes
         const uint32_t magic = PF > 1 ? (uint32_t)((0x100000000ull + PF - 1) / PF) : 0u;   // q / PF for q < 2^16
-        for (uint32_t q0 = 0; q0 < nslots; q0 += 64) {    // every lane takes part in the cross-lane reads
-            const uint32_t q = q0 + lane < nslots ? q0 + lane : nslots - 1;
-            const uint32_t r = PF > 1 ? __umulhi(q, magic) : q, k = q - r * PF;
-            const uint32_t len = (uint32_t)__shfl((int)t_len, (int)r), dr = (uint32_t)__shfl((int)d_rel, (int)r);
-            const uint64_t sv = sl_shfl64(t_src, r);
-            const uint32_t p = 16 * k;
-            if (q0 + lane >= nslots || p >= len) continue;
-            const uint8_t* s = in + (sv & ~MINUS);
-            uint8_t* o = stage + dr;
-            if (!(sv & MINUS)) {
-                uint4 v;
-                if (p + 16 <= len) { v = ldu16(s + p); __builtin_memcpy(o + p, &v, 16); }
-                else if (len >= 16) { v = ldu16(s + len - 16); __builtin_memcpy(o + len - 16, &v, 16); }
-                else for (uint32_t b = p; b < len; b++) o[b] = s[b];
-            } else {
-                // out[j] = lut[s[len - 1 - j]]: the piece [p, p + 16) is the window [len - p - 16, len - p) reversed
-                uint4 v;
-                if (p + 16 <= len) {
-                    v = reverse16(ldu16(s + (len - p - 16)));
-                    if (COMP) v = map16(v, s_lut);
-                    __builtin_memcpy(o + p, &v, 16);
-                } else if (len >= 16) {                   // the slice's last 16 output bytes = its first 16 source bytes
-                    v = reverse16(ldu16(s));
-                    if (COMP) v = map16(v, s_lut);
-                    __builtin_memcpy(o + len - 16, &v, 16);
-                } else {
-                    for (uint32_t b = p; b < len; b++) { const uint8_t c = s[len - 1 - b]; o[b] = COMP ? s_lut[c] : c; }
+        // PU rounds of slots at a time, the loads of all of them ahead of the first write to the stage
+        constexpr int PU = 4;
+        for (uint32_t q0 = 0; q0 < nslots; q0 += 64 * PU) {   // every lane takes part in the cross-lane reads
+            uint4 v[PU];
+            uint32_t at[PU];
+            bool act[PU], minus[PU];
+#pragma unroll
+            for (int u = 0; u < PU; u++) {
+                const uint32_t qq = q0 + 64 * u + lane;
+                const uint32_t q = qq < nslots ? qq : nslots - 1;
+                const uint32_t r = PF > 1 ? __umulhi(q, magic) : q, k = q - r * PF;
+                const uint32_t len = (uint32_t)__shfl((int)t_len, (int)r), dr = (uint32_t)__shfl((int)d_rel, (int)r);
+                const uint64_t sv = sl_shfl64(t_src, r);
+                const uint32_t p = 16 * k;
+                const bool in_slice = qq < nslots && p < len;
+                const uint8_t* s = in + (sv & ~MINUS);
+                minus[u] = (sv & MINUS) != 0;
+                act[u] = in_slice && len >= 16;
+                // the piece [p, p + 16), or the slice's last 16 bytes once more; on the minus strand out[j] =
+                // lut[s[len - 1 - j]], so the piece at output offset t is the window [len - t - 16, len - t) reversed
+                const uint32_t t = p + 16 <= len ? p : len - 16;
+                at[u] = dr + t;
+                v[u] = act[u] ? ldu16(s + (minus[u] ? len - t - 16 : t)) : make_uint4(0, 0, 0, 0);
+                if (in_slice && len < 16) {
+                    uint8_t* o = stage + dr;
+                    if (!minus[u]) for (uint32_t b = 0; b < len; b++) o[b] = s[b];
+                    else for (uint32_t b = 0; b < len; b++) { const uint8_t c = s[len - 1 - b]; o[b] = COMP ? s_lut[c] : c; }
                 }
+            }
+#pragma unroll
+            for (int u = 0; u < PU; u++) {
+                if (!act[u]) continue;
+                uint4 w = v[u];
+                if (minus[u]) {
+                    w = reverse16(w);
+                    if (COMP) w = map16(w, s_lut);
+                }
+                __builtin_memcpy(stage + at[u], &w, 16);
             }
         }
         wave_lds_handover();
