@@ -300,6 +300,8 @@ __device__ __forceinline__ void copy_piece(uint8_t* __restrict__ dst, const uint
 // slot q = lane + 64 k is piece q mod PF of record q / PF.  field_of(r, L, at, src), called by all lanes
 // together (it reads across lanes), gives the field of record r: its length, its place in the stage and its
 // source.  PU rounds of slots at a time, the loads of all of them ahead of the first write to the stage.
+constexpr int FMT_ROUNDS = 1;        // slot rounds per batch in the two formatters (see k_fmt_write)
+
 template <int PU, typename F>
 __device__ __forceinline__ void flat_copy_field(uint8_t* __restrict__ stage, uint32_t lane, uint32_t n, uint32_t PF, bool wrap,
                                                 const Div32& div, F&& field_of)
@@ -382,7 +384,7 @@ __device__ __forceinline__ void write_step_flat(const FormatSeqArgs& a, uint8_t*
     for (int f = 0; f < 3; f++) {
         const uint32_t PF = f == 0 ? PN : (f == 1 ? PS : PQ);
         if (PF == 0) continue;
-        flat_copy_field<3>(stage, lane, n, PF, f != 0 && wrapped, div,
+        flat_copy_field<FMT_ROUNDS>(stage, lane, n, PF, f != 0 && wrapped, div,
                            [&](uint32_t r, uint32_t& L, uint32_t& at, const uint8_t*& src) {
             const uint32_t op_r = (uint32_t)__shfl((int)op, (int)r), len_r = (uint32_t)__shfl((int)len, (int)r);
             const uint32_t nl_r = (uint32_t)__shfl((int)nl, (int)r), srel_r = (uint32_t)__shfl((int)s_rel, (int)r);
@@ -424,6 +426,11 @@ __device__ __forceinline__ bool step_is_direct(uint64_t r, uint32_t R, uint64_t 
     return pos[rl] + size[rl] - (pos[r0] & ~15ull) > FW_STAGE;
 }
 
+// (five wavefronts per SIMD is what the stages of five workgroups leave room for; the register allocation is held
+// to that -- 96 registers, nothing spilled -- because this kernel gains more from a fifth resident wavefront than
+// from loads issued further ahead: 0.85 -> 0.77 ms on 4 M x 150 bp FASTQ, where FMT_ROUNDS = 2 at four wavefronts
+// gives 0.81 ms and at five, with spills, 0.80 ms)
+__attribute__((amdgpu_waves_per_eu(5, 5)))
 __global__ __launch_bounds__(FB) void k_fmt_write(const FormatSeqArgs a, const uint64_t* __restrict__ size,
                                                   const uint64_t* __restrict__ pos, const uint32_t* __restrict__ shown_name,
                                                   const uint64_t* __restrict__ total, uint32_t* __restrict__ n_direct,
@@ -785,7 +792,7 @@ __global__ __launch_bounds__(FB) void k_tab_rows(const FormatTabArgs a, const ui
             if ((f == 1 && !a.print_seq) || (f == 2 && !a.print_qual)) continue;
             const uint32_t PF = wave_max32(((f == 0 ? f_nl : f_len) + 15) >> 4);
             if (PF == 0) continue;
-            flat_copy_field<3>(stage, lane, n, PF, false, no_wrap, [&](uint32_t r, uint32_t& L, uint32_t& at, const uint8_t*& src) {
+            flat_copy_field<FMT_ROUNDS>(stage, lane, n, PF, false, no_wrap, [&](uint32_t r, uint32_t& L, uint32_t& at, const uint8_t*& src) {
                 const uint32_t op_r = (uint32_t)__shfl((int)op, (int)r), len_r = (uint32_t)__shfl((int)f_len, (int)r);
                 const uint32_t nl_r = (uint32_t)__shfl((int)f_nl, (int)r), srel_r = (uint32_t)__shfl((int)s_rel, (int)r);
                 const uint64_t name_r = f == 0 ? from_lane64(t_name, r) : 0;

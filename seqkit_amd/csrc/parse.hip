@@ -730,7 +730,7 @@ __global__ __launch_bounds__(PB) void k_parse_copy(const ParseState* st, uint64_
             const uint32_t nslots = (last + 1) * PF;
             const uint32_t magic = PF > 1 ? (uint32_t)((0x100000000ull + PF - 1) / PF) : 0u;   // q / PF for q < 2^16
             // PU rounds of slots at a time, the loads of all of them ahead of the first LDS write
-            constexpr int PU = 4;
+            constexpr int PU = 4;                                     // (2 and 7 measure the same)
             uint8_t* const stage0 = s_stage[wave][0];
             for (uint32_t q0 = 0; q0 < nslots; q0 += 64 * PU) {       // every lane takes part in the cross-lane reads
                 uint4 v[PU];

@@ -360,7 +360,7 @@ __global__ __launch_bounds__(SB) void k_slice_copy_flat(const uint8_t* __restric
         const uint32_t nslots = cnt * PF;                // PF >= 1: the step has bytes
         const uint32_t magic = PF > 1 ? (uint32_t)((0x100000000ull + PF - 1) / PF) : 0u;   // q / PF for q < 2^16
         // PU rounds of slots at a time, the loads of all of them ahead of the first write to the stage
-        constexpr int PU = 4;
+        constexpr int PU = 4;                                 // (2 and 6 measure the same)
         for (uint32_t q0 = 0; q0 < nslots; q0 += 64 * PU) {   // every lane takes part in the cross-lane reads
             uint4 v[PU];
             uint32_t at[PU];
