@@ -64,14 +64,32 @@ __global__ __launch_bounds__(FB) void k_fmt_sizes(const FormatSeqArgs a, uint64_
 
 // ---- exclusive scan of uint64 (block partials, one-workgroup scan of partials, apply) -------
 
+// the FSCAN_ITEMS consecutive values of a thread: 16-byte loads when all of them exist
+__device__ __forceinline__ void scan_items64(const uint64_t* __restrict__ v, uint64_t n, uint64_t base, uint64_t* x)
+{
+    static_assert(FSCAN_ITEMS % 2 == 0, "pairs of values per load");
+    if (base + FSCAN_ITEMS <= n) {
+#pragma unroll
+        for (int k = 0; k < FSCAN_ITEMS; k += 2) {
+            const uint4 t = ldu16(reinterpret_cast<const uint8_t*>(v + base + k));     // (callers' arrays: 8-byte aligned)
+            x[k] = ((uint64_t)t.y << 32) | t.x;
+            x[k + 1] = ((uint64_t)t.w << 32) | t.z;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < FSCAN_ITEMS; k++) x[k] = base + k < n ? v[base + k] : 0;
+    }
+}
+
 __global__ __launch_bounds__(FB) void k_scan_partials64(const uint64_t* __restrict__ v, uint64_t n,
                                                         uint64_t* __restrict__ part)
 {
     __shared__ uint64_t s_w[FB / 64];
     const uint64_t base = (uint64_t)blockIdx.x * FSCAN_TILE + threadIdx.x * FSCAN_ITEMS;
-    uint64_t s = 0;
+    uint64_t x[FSCAN_ITEMS], s = 0;
+    scan_items64(v, n, base, x);
 #pragma unroll
-    for (int k = 0; k < FSCAN_ITEMS; k++) if (base + k < n) s += v[base + k];
+    for (int k = 0; k < FSCAN_ITEMS; k++) s += x[k];
     for (int d = 1; d < 64; d <<= 1) s += __shfl_xor(s, d);
     if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = s;
     __syncthreads();
@@ -82,23 +100,34 @@ __global__ __launch_bounds__(FB) void k_scan_partials64(const uint64_t* __restri
     }
 }
 
+// Exclusive scan of the workgroup sums, in place, by one workgroup: rounds of 1024 consecutive entries (one per
+// thread, the next round's entry loaded before this round is scanned), a shuffle scan per wavefront, the 16
+// wavefront totals through LDS, the running total carried in registers.
 __global__ __launch_bounds__(1024) void k_scan_top64(uint64_t* __restrict__ part, uint64_t npart, uint64_t* __restrict__ total)
 {
-    __shared__ uint64_t s_p[1024];
-    const uint64_t per = (npart + 1023) / 1024;
-    const uint64_t a = threadIdx.x * per, b = a + per < npart ? a + per : npart;
-    uint64_t s = 0;
-    for (uint64_t i = a; i < b; i++) s += part[i];
-    s_p[threadIdx.x] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint64_t run = 0;
-        for (int i = 0; i < 1024; i++) { const uint64_t t = s_p[i]; s_p[i] = run; run += t; }
-        *total = run;
+    __shared__ uint64_t s_w[16];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint64_t carry = 0;
+    uint64_t nxt = threadIdx.x < npart ? part[threadIdx.x] : 0;
+    for (uint64_t base = 0; base < npart; base += 1024) {
+        const uint64_t i = base + threadIdx.x;
+        const uint64_t v = nxt;
+        nxt = i + 1024 < npart ? part[i + 1024] : 0;
+        uint64_t inc = v;
+        for (int d = 1; d < 64; d <<= 1) { const uint64_t t = __shfl_up(inc, d); if ((int)lane >= d) inc += t; }
+        if (lane == 63) s_w[wave] = inc;
+        __syncthreads();
+        uint64_t run = carry + inc - v;
+#pragma unroll
+        for (uint32_t w = 0; w < 16; w++) {
+            const uint64_t t = s_w[w];
+            if (w < wave) run += t;
+            carry += t;
+        }
+        if (i < npart) part[i] = run;
+        __syncthreads();                                  // the totals are rewritten in the next round
     }
-    __syncthreads();
-    uint64_t run = s_p[threadIdx.x];
-    for (uint64_t i = a; i < b; i++) { const uint64_t t = part[i]; part[i] = run; run += t; }
+    if (threadIdx.x == 0) *total = carry;
 }
 
 __global__ __launch_bounds__(FB) void k_scan_apply64(const uint64_t* __restrict__ v, uint64_t n,
@@ -107,8 +136,9 @@ __global__ __launch_bounds__(FB) void k_scan_apply64(const uint64_t* __restrict_
     __shared__ uint64_t s_w[FB / 64];
     const uint64_t base = (uint64_t)blockIdx.x * FSCAN_TILE + threadIdx.x * FSCAN_ITEMS;
     uint64_t x[FSCAN_ITEMS], s = 0;
+    scan_items64(v, n, base, x);
 #pragma unroll
-    for (int k = 0; k < FSCAN_ITEMS; k++) { x[k] = base + k < n ? v[base + k] : 0; s += x[k]; }
+    for (int k = 0; k < FSCAN_ITEMS; k++) s += x[k];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint64_t inc = s;
     for (int d = 1; d < 64; d <<= 1) { const uint64_t t = __shfl_up(inc, d); if ((int)lane >= d) inc += t; }
@@ -116,6 +146,16 @@ __global__ __launch_bounds__(FB) void k_scan_apply64(const uint64_t* __restrict_
     __syncthreads();
     uint64_t run = part[blockIdx.x] + inc - s;
     for (uint32_t w = 0; w < wave; w++) run += s_w[w];
+    if (base + FSCAN_ITEMS <= n) {                         // 16-byte stores
+#pragma unroll
+        for (int k = 0; k < FSCAN_ITEMS; k += 2) {
+            const uint64_t r0 = run, r1 = run + x[k];
+            const uint4 t = make_uint4((uint32_t)r0, (uint32_t)(r0 >> 32), (uint32_t)r1, (uint32_t)(r1 >> 32));
+            __builtin_memcpy(out + base + k, &t, 16);
+            run = r1 + x[k + 1];
+        }
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < FSCAN_ITEMS; k++) { if (base + k < n) out[base + k] = run; run += x[k]; }
 }

@@ -142,11 +142,14 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(const uint32_t* __restrict_
     __shared__ uint64_t s_wave[16];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint64_t carry = 0;
+    uint32_t nxt[4];                                                 // the next round's counts, loaded a round ahead
+#pragma unroll
+    for (int k = 0; k < 4; k++) nxt[k] = 4ull * threadIdx.x + k < ntile ? cnt[4ull * threadIdx.x + k] : 0u;
     for (uint64_t i0 = 0; i0 < ntile; i0 += 4096) {
         const uint64_t i = i0 + 4ull * threadIdx.x;
         uint32_t c[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) c[k] = i + k < ntile ? cnt[i + k] : 0u;
+        for (int k = 0; k < 4; k++) { c[k] = nxt[k]; nxt[k] = i + 4096 + k < ntile ? cnt[i + 4096 + k] : 0u; }
         const uint32_t mine = c[0] + c[1] + c[2] + c[3];             // < 2^32: a tile holds at most TILE newlines
         uint64_t inc = mine;
 #pragma unroll
