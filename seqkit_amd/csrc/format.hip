@@ -178,91 +178,21 @@ __device__ __forceinline__ uint64_t from_lane64(uint64_t v, uint32_t src_lane)
            (uint32_t)__shfl((int)(uint32_t)v, (int)src_lane);
 }
 
-// p / width for the positions inside one record.  Div64: plain division.  Div32: records of the LDS-staged
-// writer are shorter than 8 KiB, where one multiplication by ceil(2^32 / width) is exact
-// (p * (magic * width - 2^32) < 2^32); a width beyond that never divides anything but to 0.
-struct Div64 {
-    uint32_t width;
-    __device__ __forceinline__ uint64_t operator()(uint64_t p) const { return p / width; }
-};
+// p / width for the positions inside one record, for the records whose bases the lane-group and LDS-staged
+// writers copy (at most SKH_LONG_T = 2^15 bytes), where one multiplication by
+// ceil(2^32 / width) is exact (p * (magic * width - 2^32) < 2^32 holds for width <= 2^17); a width beyond that
+// never divides such a position but to 0.
 struct Div32 {
     uint32_t width, magic;
     __device__ __forceinline__ explicit Div32(uint32_t w)
-        : width(w), magic(w < 2 || w > 8192 ? 0u : (uint32_t)((0x100000000ull + w - 1) / w)) {}
+        : width(w), magic(w < 2 || w > 131072 ? 0u : (uint32_t)((0x100000000ull + w - 1) / w)) {}
     __device__ __forceinline__ uint32_t operator()(uint32_t p) const { return width == 1 ? p : __umulhi(p, magic); }
 };
-
-template <uint32_t G, typename T>
-__device__ __forceinline__ void copy_plain(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, T n, uint32_t j)
-{
-    for (T p = (T)j * 16; p < n; p += G * 16) {
-        if (p + 16 <= n) copy16(dst + p, src + p);
-        else if (n >= 16) copy16(dst + n - 16, src + n - 16);     // the last 16 bytes again: same values, no byte loop
-        else for (T k = p; k < n; k++) dst[k] = src[k];
-    }
-}
-
-// src[0..n) with a '\n' after every `width` bytes except after the last chunk
-template <uint32_t G, typename T, typename DIV>
-__device__ __forceinline__ void copy_wrapped(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, T n,
-                                             const DIV& div, uint32_t j)
-{
-    const uint32_t width = div.width;
-    if (width < 1 || n == 0) { copy_plain<G, T>(dst, src, n, j); return; }
-    for (T p = (T)j * 16; p < n; p += G * 16) {
-        const T last = p + 16 <= n ? p + 15 : n - 1;
-        const T l0 = (T)div(p), l1 = (T)div(last);
-        if (l0 == l1 && p + 16 <= n) {
-            copy16(dst + p + l0, src + p);
-        } else if (l1 == l0 + 1 && width >= 16 && (l0 + 1) * (T)width >= 16 && (l0 + 1) * (T)width + 16 <= n) {
-            // the chunk straddles one line break: the 16 bytes that end the line and the 16 bytes that
-            // start the next one, each as one copy (what they overlap of the neighbour chunks has the
-            // same values)
-            const T b = (l0 + 1) * (T)width;          // first base of the next line
-            copy16(dst + b - 16 + l0, src + b - 16);
-            copy16(dst + b + l1, src + b);
-        } else {
-            for (T k = p; k <= last; k++) dst[k + (T)div(k)] = src[k];
-        }
-    }
-    const T breaks = (T)div(n - 1);
-    for (T b = 1 + j; b <= breaks; b += G) dst[b * width + b - 1] = '\n';
-}
 
 template <typename T>
 __device__ __forceinline__ T wrapped_len_t(T len, uint32_t width, T breaks)
 {
     return (width < 1 || len == 0) ? len : len + breaks;
-}
-
-// One record's text at o (where its first byte goes), by the G lanes of its group; lane j of the group.
-// Bases and qualities of a record longer than SKH_LONG_T are left to k_fmt_write_long.
-template <uint32_t G, typename T, typename DIV>
-__device__ __forceinline__ void write_record_text(const FormatSeqArgs& a, uint8_t* __restrict__ o, uint64_t s, T len,
-                                                  uint32_t nl, uint64_t name, const DIV& div, uint32_t j)
-{
-    if (a.print_name) {
-        if (a.print_seq) { if (j == 0) *o = (a.empty_fasta && len == 0) ? (uint8_t)'>' : a.mark; o++; }
-        copy_plain<G, uint32_t>(o, a.text + name, nl, j);
-        if (j == 0) o[nl] = '\n';
-        o += nl + 1;
-    }
-    const bool is_long = len > SKH_LONG_T;
-    const T w = wrapped_len_t<T>(len, a.width, (a.width < 1 || len == 0) ? 0 : (T)div(len - 1));
-    if (a.print_seq) {
-        if (!is_long) copy_wrapped<G, T, DIV>(o, a.seq + s, len, div, j);
-        if (j == 0) o[w] = '\n';
-        o += w + 1;
-    }
-    if (a.print_qual && !(a.empty_fasta && len == 0)) {
-        if (a.plus_line) { if (j == 0) { o[0] = '+'; o[1] = '\n'; } o += 2; }
-        if (a.qual) {
-            if (!is_long && len) copy_wrapped<G, T, DIV>(o, a.qual + s, len, div, j);
-            if (j == 0) o[w] = '\n';
-        } else if (j == 0) {
-            o[0] = '\n';                      // no quality plane: an empty quality string
-        }
-    }
 }
 
 __device__ __forceinline__ uint32_t wave_max32(uint32_t v)
@@ -340,6 +270,65 @@ __device__ __forceinline__ void copy_piece(uint8_t* __restrict__ dst, const uint
 // slot q = lane + 64 k is piece q mod PF of record q / PF.  field_of(r, L, at, src), called by all lanes
 // together (it reads across lanes), gives the field of record r: its length, its place in the stage and its
 // source.  PU rounds of slots at a time, the loads of all of them ahead of the first write to the stage.
+// A field of n <= SKH_LONG_T bytes straight to global memory by the G lanes of a record's group (lane j): piece
+// j + G k each, the loads of four pieces ahead of the first store; the pieces write their own line breaks.
+template <uint32_t G>
+__device__ __forceinline__ void copy_field_direct(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, uint32_t n,
+                                                  bool wrapped, const Div32& div, uint32_t j)
+{
+    static_assert(SKH_LONG_T <= 32768, "Div32 is exact up to 2^15");
+    constexpr int PU = 4;
+    for (uint32_t p0 = j * 16; p0 < n; p0 += G * 16 * PU) {
+        uint4 v0[PU], v1[PU];
+#pragma unroll
+        for (int u = 0; u < PU; u++) {
+            const uint32_t p = p0 + u * G * 16;
+            v0[u] = v1[u] = make_uint4(0, 0, 0, 0);
+            if (p < n) {
+                const PiecePlan pl = plan_piece(n, p, wrapped, div);
+                if (pl.n16 >= 1) v0[u] = ldu16(src + pl.so0);
+                if (pl.n16 == 2) v1[u] = ldu16(src + pl.so1);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < PU; u++) {
+            const uint32_t p = p0 + u * G * 16;
+            if (p < n) store_piece(dst, src, n, p, wrapped, div, plan_piece(n, p, wrapped, div), v0[u], v1[u]);
+        }
+    }
+}
+
+// One record's text at o (where its first byte goes), by the G lanes of its group; lane j of the group.
+// Bases and qualities of a record longer than SKH_LONG_T are left to k_fmt_write_long.
+template <uint32_t G>
+__device__ __forceinline__ void write_record_text(const FormatSeqArgs& a, uint8_t* __restrict__ o, uint64_t s, uint64_t len,
+                                                  uint32_t nl, uint64_t name, const Div32& div, uint32_t j)
+{
+    if (a.print_name) {
+        if (a.print_seq) { if (j == 0) *o = (a.empty_fasta && len == 0) ? (uint8_t)'>' : a.mark; o++; }
+        copy_field_direct<G>(o, a.text + name, nl, false, div, j);
+        if (j == 0) o[nl] = '\n';
+        o += nl + 1;
+    }
+    const bool is_long = len > SKH_LONG_T;
+    const bool wrapped = a.width >= 1;
+    const uint64_t w = wrapped_len_t<uint64_t>(len, a.width, (!wrapped || len == 0) ? 0 : (is_long ? (len - 1) / a.width : div((uint32_t)len - 1)));
+    if (a.print_seq) {
+        if (!is_long) copy_field_direct<G>(o, a.seq + s, (uint32_t)len, wrapped, div, j);
+        if (j == 0) o[w] = '\n';
+        o += w + 1;
+    }
+    if (a.print_qual && !(a.empty_fasta && len == 0)) {
+        if (a.plus_line) { if (j == 0) { o[0] = '+'; o[1] = '\n'; } o += 2; }
+        if (a.qual) {
+            if (!is_long) copy_field_direct<G>(o, a.qual + s, (uint32_t)len, wrapped, div, j);
+            if (j == 0) o[w] = '\n';
+        } else if (j == 0) {
+            o[0] = '\n';                      // no quality plane: an empty quality string
+        }
+    }
+}
+
 constexpr int FMT_ROUNDS = 1;        // slot rounds per batch in the two formatters (see k_fmt_write)
 
 template <int PU, typename F>
@@ -536,7 +525,7 @@ __global__ __launch_bounds__(FB) void k_fmt_write_direct(const FormatSeqArgs a, 
     const uint32_t leader = (threadIdx.x & 63) & ~(G - 1);
     const uint32_t R = fmt_records_per_step(tot, a.nrec);
     const bool all_direct = all_steps_direct(tot, a.nrec);
-    const Div64 div{a.width};
+    const Div32 div(a.width);
     for (uint64_t r = ((uint64_t)blockIdx.x * FB + threadIdx.x) / G; r < a.nrec; r += (uint64_t)gridDim.x * (FB / G)) {
         uint64_t m_size = 0, m_pos = 0, m_s = 0, m_e = 0, m_name = 0;
         uint32_t m_nl = 0;
@@ -549,7 +538,7 @@ __global__ __launch_bounds__(FB) void k_fmt_write_direct(const FormatSeqArgs a, 
         }
         if (from_lane64(m_size, leader) == 0) continue;
         const uint64_t s = from_lane64(m_s, leader), len = from_lane64(m_e, leader) - s;
-        write_record_text<G, uint64_t, Div64>(a, out + from_lane64(m_pos, leader), s, len, __shfl(m_nl, leader),
+        write_record_text<G>(a, out + from_lane64(m_pos, leader), s, len, __shfl(m_nl, leader),
                                               from_lane64(m_name, leader), div, j);
     }
 }
@@ -866,6 +855,7 @@ __global__ __launch_bounds__(FB) void k_tab_write(const FormatTabArgs a, const u
     const uint32_t leader = (threadIdx.x & 63) & ~(G - 1);
     const uint32_t R = fmt_records_per_step(tot, a.nrec);
     const bool all_direct = all_steps_direct(tot, a.nrec);
+    const Div32 no_wrap(0);
     for (uint64_t r = ((uint64_t)blockIdx.x * FB + threadIdx.x) / G; r < a.nrec; r += (uint64_t)gridDim.x * (FB / G)) {
         uint64_t m_pos = 0, m_s = 0, m_e = 0, m_name = 0;
         uint32_t m_nl = 0, m_take = 0;
@@ -876,14 +866,14 @@ __global__ __launch_bounds__(FB) void k_tab_write(const FormatTabArgs a, const u
         uint8_t* o = out + from_lane64(m_pos, leader);
         const uint64_t s = from_lane64(m_s, leader), len = from_lane64(m_e, leader) - s;
         const uint32_t nl = __shfl(m_nl, leader);
-        copy_plain<G, uint32_t>(o, a.text + from_lane64(m_name, leader), nl, j);
+        copy_field_direct<G>(o, a.text + from_lane64(m_name, leader), nl, false, no_wrap, j);
         if (j == 0) o[nl] = '\t';
         o += nl + 1;
         const bool is_long = len > SKH_LONG_T;           // bases and qualities: k_tab_write_long
-        if (a.print_seq) { if (!is_long) copy_plain<G, uint64_t>(o, a.seq + s, len, j); o += len; }
+        if (a.print_seq) { if (!is_long) copy_field_direct<G>(o, a.seq + s, (uint32_t)len, false, no_wrap, j); o += len; }
         if (j == 0) *o = '\t';
         o++;
-        if (a.print_qual) { if (!is_long) copy_plain<G, uint64_t>(o, a.qual + s, len, j); o += len; }
+        if (a.print_qual) { if (!is_long) copy_field_direct<G>(o, a.qual + s, (uint32_t)len, false, no_wrap, j); o += len; }
     }
 }
 
