@@ -235,7 +235,7 @@ def test_long_lines_and_long_reads(cli, oracle_cli, tmp_path):
     # FASTA (one line per record), long FASTQ reads, every wrap width, fx2tab with sequence columns
     import numpy as np
     rng = np.random.default_rng(9)
-    lens = [32767, 32768, 32769, 12, 65536 + 7, 0, 300001, 98304, 1]
+    lens = [32767, 32768, 32769, 12, 65536 + 7, 0, 300001, 98304, 1, 20000, 30011, 8192, 16385]
     fa, fq = tmp_path / "unwrapped.fa", tmp_path / "long.fq"
     with open(fa, "wb") as fh, open(fq, "wb") as fh2:
         for i, n in enumerate(lens):
@@ -247,6 +247,9 @@ def test_long_lines_and_long_reads(cli, oracle_cli, tmp_path):
     for f in (fa, fq):
         for argv in (["seq", "-r", "-p"], ["seq", "-w", "0"], ["seq", "-r", "-w", "7"], ["seq", "-p", "-w", "32768"],
                      ["seq", "-s", "-w", "100"], ["seq", "-r", "-p", "--batch-bytes", "100000"],
+                     # widths around the limits of the writers' multiply-high line index (and far beyond any record)
+                     ["seq", "-w", "8191"], ["seq", "-r", "-w", "8192"], ["seq", "-w", "8193"], ["seq", "-p", "-w", "10000"],
+                     ["seq", "-w", "16384"], ["seq", "-w", "131072"], ["seq", "-w", "131073"], ["seq", "-w", "1000000"],
                      ["fx2tab"], ["fx2tab", "-l", "-g"], ["fx2tab", "-n", "-l", "-B", "AT"], ["stats", "-a", "-T"]):
             want = run_cli(oracle_cli, [a for a in argv if a not in ("--batch-bytes", "100000")] + [str(f)])
             got = run_cli(cli, argv + [str(f)])
