@@ -623,6 +623,32 @@ __device__ __forceinline__ uint64_t shfl64(uint64_t v, uint32_t src_lane)
            (uint32_t)__shfl((int)(uint32_t)v, (int)src_lane);
 }
 
+// One line of at least WIDE_LINE bytes, by all 64 lanes of a wavefront: the stores are aligned 16-byte chunks of
+// the plane (the bytes before the first whole chunk go one per lane, the end of the line as its last 16 bytes
+// once more), the loads take any alignment; the loads of four rounds of chunks go out before the first store.
+constexpr uint32_t WIDE_LINE = 512;
+
+__device__ __forceinline__ void copy_line_wave(uint8_t* __restrict__ out, const uint8_t* __restrict__ src, uint32_t len,
+                                               uint32_t lane)
+{
+    const uint32_t head = (uint32_t)(-reinterpret_cast<uintptr_t>(out)) & 15u;       // len >= WIDE_LINE > head + 16
+    if (lane < head) out[lane] = src[lane];
+    constexpr int PU = 4;
+    for (uint32_t p0 = head + lane * 16; p0 < len; p0 += 64 * 16 * PU) {
+        uint4 v[PU];
+#pragma unroll
+        for (int u = 0; u < PU; u++) {
+            const uint32_t p = p0 + u * 1024;
+            v[u] = p < len ? ldu16(src + (p + 16 <= len ? p : len - 16)) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < PU; u++) {
+            const uint32_t p = p0 + u * 1024;
+            if (p < len) { const uint4 t = v[u]; __builtin_memcpy(out + (p + 16 <= len ? p : len - 16), &t, 16); }
+        }
+    }
+}
+
 // One line's bytes, by the G lanes of its group (lane j): 16-byte pieces at any alignment, the end of the
 // line as its last 16 bytes copied once more (same values, no byte loop).
 template <uint32_t G>
@@ -713,8 +739,16 @@ __global__ __launch_bounds__(PB) void k_parse_copy(const ParseState* st, uint64_
                 const uint32_t i = base + grp;
                 const uint32_t len = (uint32_t)__shfl((int)t_len, (int)i), q = (uint32_t)__shfl((int)t_q, (int)i);
                 const uint64_t dst = shfl64(t_dst, i), start = shfl64(t_start, i);
-                if (len == 0 || len > LONG_LINE) continue;             // (an item that is not valid has len 0)
+                if (len == 0 || len >= WIDE_LINE) continue;            // (an item that is not valid has len 0)
                 copy_line<G>((FASTQ && q ? qual : seq) + dst, text + start, len, j);
+            }
+            // lines of half a kilobyte and more, one after the other by the whole wavefront
+            unsigned long long wide = __ballot(valid && t_len >= WIDE_LINE && t_len <= LONG_LINE);
+            while (wide) {
+                const uint32_t i = (uint32_t)__builtin_ctzll(wide);
+                wide &= wide - 1;
+                const uint32_t len = (uint32_t)__shfl((int)t_len, (int)i), q = (uint32_t)__shfl((int)t_q, (int)i);
+                copy_line_wave((FASTQ && q ? qual : seq) + shfl64(t_dst, i), text + shfl64(t_start, i), len, lane);
             }
             continue;
         }
