@@ -100,7 +100,14 @@ skh::LaunchCfg cfg_for(const skh_ctx* ctx, uint64_t nrec, uint64_t total)
     const uint64_t mean_len = nrec ? total / nrec : 0;
     c.span_u = ctx->span_u >= 0 ? ctx->span_u : 0;
     c.fuse_fastq = ctx->fuse_fastq;
-    c.staged = ctx->staged >= 0 ? ctx->staged : (mean_len < 300 ? 1 : 0);
+    c.staged = ctx->staged >= 0 ? (ctx->staged != 0) : (mean_len < 300 ? 1 : 0);
+    // The flat kernel (SKH_STAGED = 2 forces it, 0 / 1 switch it off), % of HBM peak against the choice above on
+    // the same machine: reads of 100 bases 64-66 / 56, 250 bases 65 / 62, 30-151 bases 53 / 48, 350 +- 70: 61 / 56,
+    // 1000 +- 200: 62 / 57, 2000 +- 400: 63 / 59; level at 50, 75 and 150 bases (150: 63.1 / 63.7, left with the
+    // staged kernel); behind from 4000 +- 800 on (58.5 / 61), where a step is one record, and on nanopore-like
+    // lengths (57.5 / 61), whose records beyond the stage it writes straight to global memory.
+    c.flat = ctx->staged >= 0 ? (ctx->staged == 2) : (mean_len < 128 || (mean_len >= 192 && mean_len < 3000));
+    c.flat_steps = ctx->staged_steps;
     // staged reverse kernel, steps per wavefront (SKH_STAGED_STEPS overrides).  Measured on batches of
     // 5-10 M records: 150-base reads fastest with 2; 250-base reads 58 -> 63 % of HBM peak with 3;
     // reads of about 100 bases and ragged 30-151-base reads gain 4-5 points with 6, where fewer of

@@ -22,7 +22,10 @@ struct LaunchCfg {
     uint32_t max_grid;   // optional cap on workgroups of a grid-stride launch (0 = none)
     uint32_t n_cu;       // compute units of the device
     int staged;          // reverse, short records: 1 = LDS-staged kernel, 0 = direct (lane exchange) kernel
+    int flat;            // reverse out of place: 1 = the flat kernel (pieces of all records of a step dealt over the lanes)
+                         // instead of either
     uint32_t staged_steps;   // staged kernel: steps per wavefront (0 = default)
+    uint32_t flat_steps;     // flat kernel: steps per wavefront (0 = default)
     uint32_t short_steps;    // direct reverse kernel: steps per wavefront (0 = about 32 KiB of plane per workgroup)
     uint32_t count_steps;    // short count kernel: steps per wavefront (0 = default)
     uint32_t stats_steps;    // stats kernel: runs of chunks per workgroup (0 = default)

@@ -913,6 +913,177 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_reverse_staged(const uint8_t* __r
 }
 
 // Long records: one aligned run of LONG_RUN bytes of the plane per workgroup (see for_each_long).
+// ------------------------------------------------------------------ reverse, flat form
+//
+// The output of consecutive records is one contiguous stretch of the plane.  A wavefront takes R records per
+// step (as many as fit its LDS stage by the mean length, at most 64; lane i holds the offsets of record i) and
+// deals the 16-byte pieces of ALL of them over its 64 lanes: every record gets PF piece slots (the most any
+// record of the step needs), slot q = lane + 64 k is piece q mod PF of record q / PF.  A piece at offset t of
+// a record of length len is the source window [len - t - 16, len - t) of the same record, byte-reversed (and
+// complemented); the end of a record goes as its last 16 output bytes once more.  The pieces are put together
+// in the stage, which costs nothing at any byte offset, and the stretch leaves as aligned 16-byte chunks in
+// whole-wavefront rows.  The work per piece does not depend on where records begin and end inside a chunk.
+// A step that does not fit the stage is written record by record by the whole wavefront, straight to global
+// memory; records beyond SKH_LONG_T are left to k_reverse_tiles.
+constexpr uint32_t RF_STAGE = 7 * 1024;        // (4 and 5 KiB: 3-6 points slower on 150-base reads)
+
+__host__ __device__ inline uint32_t flat_records_per_step(uint64_t total, uint64_t nrec)
+{
+    const uint64_t r = (RF_STAGE - 64) * 7 / 8 / (nrec ? total / nrec + 1 : 1);
+    return r < 1 ? 1u : (r > 64 ? 64u : (uint32_t)r);
+}
+
+__device__ __forceinline__ uint64_t shfl64u(uint64_t v, uint32_t src_lane)
+{
+    return ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(v >> 32), (int)src_lane) << 32) |
+           (uint32_t)__shfl((int)(uint32_t)v, (int)src_lane);
+}
+
+template <bool COMP>
+__global__ __launch_bounds__(SKH_BLOCK) void k_reverse_flat(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                            const uint64_t* __restrict__ offs, uint64_t total,
+                                                            uint64_t nrec, Table256 lut, uint32_t steps,
+                                                            BatchHint* __restrict__ hint)
+{
+    __shared__ uint8_t s_lut[256];
+    __shared__ __attribute__((aligned(16))) uint8_t s_stage[SKH_BLOCK / 64][RF_STAGE + 32];
+    __shared__ uint8_t s_owner[SKH_BLOCK / 64][RF_STAGE / 16 + 64];       // a stage holds RF_STAGE / 16 whole pieces + one partial per record
+    static_assert(SKH_BLOCK == 256, "one table byte per thread");
+    s_lut[threadIdx.x] = lut.v[threadIdx.x];
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr uint32_t NWAVE = SKH_BLOCK / 64;
+    const uint32_t R = flat_records_per_step(total, nrec);
+    const uint64_t nsteps = (nrec + R - 1) / R;
+    const uint32_t pf_cap = (uint32_t)((2 * (total / nrec) + 15) >> 4) + 1;      // nrec != 0: the grid is not empty
+    // workgroup b serves the steps * NWAVE consecutive steps from b * steps * NWAVE on, its wavefronts interleaved
+    const uint64_t step_first = (uint64_t)blockIdx.x * steps * NWAVE + wave;
+    const uint64_t step_stop = (uint64_t)(blockIdx.x + 1) * steps * NWAVE;
+    const uint64_t step_end = step_stop < nsteps ? step_stop : nsteps;
+    uint8_t* stage = s_stage[wave];
+    for (uint64_t step = step_first; step < step_end; step += NWAVE) {
+        const uint64_t i0 = step * R;
+        const uint32_t cnt = nrec - i0 < R ? (uint32_t)(nrec - i0) : R;
+        uint64_t t_o = 0, t_e = 0;
+        if (lane < cnt) { t_o = offs[i0 + lane]; t_e = offs[i0 + lane + 1]; }
+        const uint64_t p0 = shfl64u(t_o, 0), p1 = shfl64u(t_e, cnt - 1);
+        if (p1 == p0) continue;
+        const uint64_t a0 = p0 & ~15ull;
+        if (p1 - a0 > RF_STAGE) {                        // wave-uniform: record by record, straight to global memory
+            for (uint32_t i = 0; i < cnt; i++) {
+                const uint64_t s = shfl64u(t_o, i), e = shfl64u(t_e, i);
+                if (e - s > SKH_LONG_T) {
+                    // k_reverse_tiles writes the chunks that end inside the record: the bytes of its last, partial
+                    // chunk are written here
+                    if (lane == 0) atomicAdd(&hint->n_long, 1u);
+                    const uint64_t x = (e & ~15ull) + lane;
+                    if (x < e) { const uint8_t c = in[s + (e - 1 - x)]; out[x] = COMP ? s_lut[c] : c; }
+                    continue;
+                }
+                const uint32_t len = (uint32_t)(e - s);
+                if (len < 16) {
+                    if (lane < len) { const uint8_t c = in[e - 1 - lane]; out[s + lane] = COMP ? s_lut[c] : c; }
+                    continue;
+                }
+                for (uint32_t p = lane * 16; p < len; p += 1024) {
+                    const uint32_t t = p + 16 <= len ? p : len - 16;
+                    uint4 v = reverse16(ldu16(in + s + (len - t - 16)));
+                    if (COMP) v = map16(v, s_lut);
+                    __builtin_memcpy(out + s + t, &v, 16);
+                }
+            }
+            continue;
+        }
+        const uint32_t t_len = (uint32_t)(t_e - t_o), d_rel = (uint32_t)(t_o - a0), s_rel = (uint32_t)(t_o - p0);
+        const uint32_t pieces = (t_len + 15) >> 4;
+        uint32_t PF = pieces;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)PF, d); PF = t > PF ? t : PF; }
+        // (a few records far longer than the rest would leave most slots empty: slots for twice the mean length,
+        // what a record has beyond them is copied after the slots)
+        PF = PF < pf_cap ? PF : pf_cap;
+        // Records of unequal lengths would leave many of the cnt * PF slots empty: then every record gets as many
+        // slots as it has pieces (at most PF), and a byte table in LDS, filled by the records' own lanes, says
+        // which record a slot belongs to.
+        // (decided on the step's byte count: its pieces number between bytes / 16 and bytes / 16 + cnt)
+        const uint32_t est = ((uint32_t)(p1 - p0) >> 4) + (cnt >> 1);
+        const bool ragged = cnt * PF > est + (est >> 2);                // wave-uniform
+        uint8_t* owner = s_owner[wave];
+        uint32_t pre = 0, npieces = 0;
+        if (ragged) {
+            const uint32_t mine = pieces < PF ? pieces : PF;
+            uint32_t incl = mine;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, d); if ((int)lane >= d) incl += t; }
+            npieces = (uint32_t)__shfl((int)incl, 63);
+            pre = incl - mine;
+            for (uint32_t k = 0; k < mine; k++) owner[pre + k] = (uint8_t)lane;
+            wave_lds_handover();
+        }
+        const uint32_t nslots = ragged ? npieces : cnt * PF;           // PF >= 1: the step has bytes
+        const uint32_t magic = PF > 1 ? (uint32_t)((0x100000000ull + PF - 1) / PF) : 0u;   // q / PF for q < 2^16
+        const uint8_t* src0 = in + p0;
+        constexpr int PU = 4;                            // rounds of slots whose loads go out together (2: level, 7: slower)
+        for (uint32_t q0 = 0; q0 < nslots; q0 += 64 * PU) {   // every lane takes part in the cross-lane reads
+            uint4 v[PU];
+            uint32_t at[PU];
+            bool act[PU];
+#pragma unroll
+            for (int u = 0; u < PU; u++) {
+                const uint32_t qq = q0 + 64 * u + lane;
+                const uint32_t q = qq < nslots ? qq : nslots - 1;
+                uint32_t r, k;
+                if (ragged) {
+                    r = owner[q];
+                    k = q - (uint32_t)__shfl((int)pre, (int)r);
+                } else {
+                    r = PF > 1 ? __umulhi(q, magic) : q;
+                    k = q - r * PF;
+                }
+                const uint32_t len = (uint32_t)__shfl((int)t_len, (int)r), dr = (uint32_t)__shfl((int)d_rel, (int)r);
+                const uint32_t sr = (uint32_t)__shfl((int)s_rel, (int)r);
+                const uint32_t p = 16 * k;
+                const bool in_rec = qq < nslots && p < len;
+                act[u] = in_rec && len >= 16;
+                const uint32_t t = p + 16 <= len ? p : len - 16;
+                at[u] = dr + t;
+                v[u] = act[u] ? ldu16(src0 + sr + (len - t - 16)) : make_uint4(0, 0, 0, 0);
+                if (in_rec && len < 16)
+                    for (uint32_t b = 0; b < len; b++) { const uint8_t c = src0[sr + len - 1 - b]; stage[dr + b] = COMP ? s_lut[c] : c; }
+            }
+#pragma unroll
+            for (int u = 0; u < PU; u++) {
+                if (!act[u]) continue;
+                uint4 w = reverse16(v[u]);
+                if (COMP) w = map16(w, s_lut);
+                __builtin_memcpy(stage + at[u], &w, 16);
+            }
+        }
+        unsigned long long more = __ballot(pieces > PF);
+        while (more) {                                   // the pieces of a long record beyond its slots, by the whole wavefront
+            const uint32_t i = (uint32_t)__builtin_ctzll(more);
+            more &= more - 1;
+            const uint32_t len = (uint32_t)__shfl((int)t_len, (int)i), dr = (uint32_t)__shfl((int)d_rel, (int)i);
+            const uint32_t sr = (uint32_t)__shfl((int)s_rel, (int)i);
+            for (uint32_t p = 16 * (PF + lane); p < len; p += 1024) {      // len > 16 PF >= 16
+                const uint32_t t = p + 16 <= len ? p : len - 16;
+                uint4 w = reverse16(ldu16(src0 + sr + (len - t - 16)));
+                if (COMP) w = map16(w, s_lut);
+                __builtin_memcpy(stage + dr + t, &w, 16);
+            }
+        }
+        wave_lds_handover();
+        const uint32_t nbytes = (uint32_t)(p1 - a0), head = (uint32_t)(p0 - a0);
+        const uint32_t c_lo = head ? 16u : 0u, c_hi = nbytes & ~15u;
+        for (uint32_t c = lane * 16; c < c_hi; c += 1024)
+            if (c >= c_lo) *reinterpret_cast<uint4*>(out + a0 + c) = *reinterpret_cast<const uint4*>(stage + c);
+        if (head && lane >= head && lane < 16 && lane < nbytes) out[a0 + lane] = stage[lane];
+        if (c_hi < nbytes && (c_hi != 0 || !head) && lane < nbytes - c_hi) out[a0 + c_hi + lane] = stage[c_hi + lane];
+        wave_lds_handover();
+    }
+}
+
 template <bool COMP, bool FASTQ>
 __global__ __launch_bounds__(SKH_BLOCK) void k_reverse_tiles(RevPlanes P, uint64_t nrec, Table256 lut,
                                                              const BatchHint* __restrict__ hint)
@@ -1870,7 +2041,17 @@ static hipError_t launch_reverse_t(const LaunchCfg& cfg, const uint8_t* in, uint
 {
     const RevPlanes P{in, out, qin, qout, offs, total};
     if (cfg.span_u && !FASTQ) return launch_reverse_span_t<COMP>(cfg, P, nrec, lut, st);
-    if (cfg.staged && !FASTQ) {
+    if (cfg.flat && !FASTQ) {
+        // steps per wavefront: 1 to 3 measure within two points of each other on every read length (100-base
+        // reads best with 1, ragged reads with 2 to 3), more are slower
+        const uint32_t steps = cfg.flat_steps ? cfg.flat_steps : 2;
+        const uint32_t R = flat_records_per_step(total, nrec);
+        const uint64_t nsteps = (nrec + R - 1) / R, per_block = (uint64_t)steps * (SKH_BLOCK / 64);
+        const uint64_t g1 = (nsteps + per_block - 1) / per_block;
+        if (g1 > 0x7fffffffull) return hipErrorInvalidValue;
+        if (g1) hipLaunchKernelGGL((k_reverse_flat<COMP>), dim3((uint32_t)g1), dim3(SKH_BLOCK), 0, st, P.in, P.out, P.offs,
+                                   P.total, nrec, lut, steps, hint);
+    } else if (cfg.staged && !FASTQ) {
         const uint32_t steps = cfg.staged_steps ? cfg.staged_steps : 2;   // steps per wavefront
         const uint64_t per_block = (uint64_t)steps * (SKH_BLOCK >> cfg.logG);
         const uint64_t g1 = (nrec + per_block - 1) / per_block;

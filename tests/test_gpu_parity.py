@@ -24,7 +24,9 @@ def lib():
 
 # every reverse implementation must give the same bytes; the variables are read by skh_init
 KERNEL_SETS = {
-    "staged": {"SKH_SPAN_U": "0", "SKH_STAGED": "1"},                # LDS-staged lane groups (default for short reads)
+    "staged": {"SKH_SPAN_U": "0", "SKH_STAGED": "1"},                # LDS-staged lane groups (default for reads of 128-191 bases)
+    "flat": {"SKH_SPAN_U": "0", "SKH_STAGED": "2"},                  # pieces of all records of a step dealt over the lanes, rows
+                                                                     # put together in LDS (default below 3000 bases otherwise)
     "span": {"SKH_SPAN_U": "4"},                                     # lanes own consecutive output chunks (on request only)
     "direct": {"SKH_SPAN_U": "0", "SKH_STAGED": "0"},                # lane groups without LDS staging (default from 300 bases on)
     "fused": {"SKH_SPAN_U": "0", "SKH_STAGED": "0", "SKH_FUSE_FASTQ": "1"},   # bases and qualities in one launch
@@ -204,6 +206,42 @@ def test_every_group_width(lib, ora, logg, count_u, monkeypatch):
         assert np.array_equal(run_count(lib, c, seq, offs, cls, 5), ora.count(seq, offs, cls, 5))
     finally:
         lib.skh_destroy(c)
+
+
+def test_flat_kernel_step_shapes(lib, ora, monkeypatch):
+    # The flat reverse kernel takes as many records per step as fit its 7-KiB LDS stage by the batch's MEAN length:
+    # batches whose steps are even, ragged (slot table in LDS), hold records far beyond twice the mean (copied
+    # after the slots), do not fit the stage (written record by record) or hold records beyond 32 KiB (whose last
+    # partial chunk this kernel writes, the rest the long-record kernel), with empty and tiny records in between.
+    monkeypatch.setenv("SKH_STAGED", "2")
+    monkeypatch.setenv("SKH_SPAN_U", "0")
+    rng = np.random.default_rng(5)
+    batches = {
+        "even150": np.full(3000, 150),
+        "ragged30_151": rng.integers(30, 152, 5000),
+        "heavy_tail": np.clip(np.exp(rng.normal(np.log(100), 0.6, 5000)), 1, 6000).astype(np.int64),
+        "one_long_per_step": np.where(np.arange(4000) % 37 == 0, 2500, rng.integers(0, 90, 4000)),
+        "overflowing_steps": np.where(np.arange(3000) % 50 < 5, 7000, 40),
+        "around_the_stage": np.array([7167, 7168, 7169, 7100, 15, 16, 17, 0, 7184, 1, 3584, 3584, 10000, 31, 32, 33] * 20),
+        "long_records_between": np.concatenate([rng.integers(0, 300, 500), [40000, 0, 33000, 17, 32768, 32769, 5, 100001, 3], rng.integers(0, 40, 300)]),
+        "kilobases": rng.integers(800, 2400, 400),
+        "single": np.array([150]),
+        "all_empty": np.zeros(100, np.int64),
+    }
+    for steps in ("1", "3"):                           # steps per wavefront
+        monkeypatch.setenv("SKH_STAGED_STEPS", steps)
+        c = lib.init(0)
+        try:
+            for name, lengths in batches.items():
+                seq, qual, offs = make_batch(np.asarray(lengths, np.int64), seed=len(name), letters=SOFT, with_qual=True)
+                total = int(offs[-1])
+                lut = ora.pair_table(3)
+                want_s, want_q = ora.transform(seq, qual, offs, lut, True)
+                got_s, got_q = run_revcomp(lib, c, seq, qual, offs, lut, True)
+                assert np.array_equal(got_s[:total], want_s[:total]), (name, steps)
+                assert np.array_equal(got_q[:total], want_q[:total]), (name, steps)
+        finally:
+            lib.skh_destroy(c)
 
 
 def run_count(lib, ctx, seq, offs, class_of, nclass):
