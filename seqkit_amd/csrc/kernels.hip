@@ -927,9 +927,9 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_reverse_staged(const uint8_t* __r
 // memory; records beyond SKH_LONG_T are left to k_reverse_tiles.
 constexpr uint32_t RF_STAGE = 7 * 1024;        // (4 and 5 KiB: 3-6 points slower on 150-base reads)
 
-__host__ __device__ inline uint32_t flat_records_per_step(uint64_t total, uint64_t nrec)
+__host__ __device__ inline uint32_t flat_records_per_step(uint64_t mean_len)
 {
-    const uint64_t r = (RF_STAGE - 64) * 7 / 8 / (nrec ? total / nrec + 1 : 1);
+    const uint64_t r = (RF_STAGE - 64) * 7 / 8 / (mean_len + 1);
     return r < 1 ? 1u : (r > 64 ? 64u : (uint32_t)r);
 }
 
@@ -943,7 +943,7 @@ template <bool COMP>
 __global__ __launch_bounds__(SKH_BLOCK) void k_reverse_flat(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
                                                             const uint64_t* __restrict__ offs, uint64_t total,
                                                             uint64_t nrec, Table256 lut, uint32_t steps,
-                                                            BatchHint* __restrict__ hint)
+                                                            BatchHint* __restrict__ hint, int use_hint)
 {
     __shared__ uint8_t s_lut[256];
     __shared__ __attribute__((aligned(16))) uint8_t s_stage[SKH_BLOCK / 64][RF_STAGE + 32];
@@ -954,9 +954,17 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_reverse_flat(const uint8_t* __res
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     constexpr uint32_t NWAVE = SKH_BLOCK / 64;
-    const uint32_t R = flat_records_per_step(total, nrec);
+    // The grid is sized for the records per step that the batch's mean length gives.  A few very long records among
+    // short reads raise that mean: the mean of the sampled short records then gives more records per step, and the
+    // last workgroups of the grid find nothing left to do.
+    uint64_t mean_len = total / nrec;                    // nrec != 0: the grid is not empty
+    uint32_t R = flat_records_per_step(mean_len);
+    if (use_hint) {
+        const uint32_t mean_short = __builtin_amdgcn_readfirstlane(hint->mean_short);
+        if (mean_short != ~0u && flat_records_per_step(mean_short) > R) { R = flat_records_per_step(mean_short); mean_len = mean_short; }
+    }
     const uint64_t nsteps = (nrec + R - 1) / R;
-    const uint32_t pf_cap = (uint32_t)((2 * (total / nrec) + 15) >> 4) + 1;      // nrec != 0: the grid is not empty
+    const uint32_t pf_cap = (uint32_t)((2 * mean_len + 15) >> 4) + 1;
     // workgroup b serves the steps * NWAVE consecutive steps from b * steps * NWAVE on, its wavefronts interleaved
     const uint64_t step_first = (uint64_t)blockIdx.x * steps * NWAVE + wave;
     const uint64_t step_stop = (uint64_t)(blockIdx.x + 1) * steps * NWAVE;
@@ -2045,12 +2053,12 @@ static hipError_t launch_reverse_t(const LaunchCfg& cfg, const uint8_t* in, uint
         // steps per wavefront: 1 to 3 measure within two points of each other on every read length (100-base
         // reads best with 1, ragged reads with 2 to 3), more are slower
         const uint32_t steps = cfg.flat_steps ? cfg.flat_steps : 2;
-        const uint32_t R = flat_records_per_step(total, nrec);
+        const uint32_t R = flat_records_per_step(nrec ? total / nrec : 0);
         const uint64_t nsteps = (nrec + R - 1) / R, per_block = (uint64_t)steps * (SKH_BLOCK / 64);
         const uint64_t g1 = (nsteps + per_block - 1) / per_block;
         if (g1 > 0x7fffffffull) return hipErrorInvalidValue;
         if (g1) hipLaunchKernelGGL((k_reverse_flat<COMP>), dim3((uint32_t)g1), dim3(SKH_BLOCK), 0, st, P.in, P.out, P.offs,
-                                   P.total, nrec, lut, steps, hint);
+                                   P.total, nrec, lut, steps, hint, cfg.use_hint);
     } else if (cfg.staged && !FASTQ) {
         const uint32_t steps = cfg.staged_steps ? cfg.staged_steps : 2;   // steps per wavefront
         const uint64_t per_block = (uint64_t)steps * (SKH_BLOCK >> cfg.logG);
