@@ -24,6 +24,7 @@ struct LaunchCfg {
     int staged;          // reverse, short records: 1 = LDS-staged kernel, 0 = direct (lane exchange) kernel
     int flat;            // reverse out of place: 1 = the flat kernel (pieces of all records of a step dealt over the lanes)
                          // instead of either
+    int flat_inplace;    // the same choice for the in-place form
     uint32_t staged_steps;   // staged kernel: steps per wavefront (0 = default)
     uint32_t flat_steps;     // flat kernel: steps per wavefront (0 = default)
     uint32_t short_steps;    // direct reverse kernel: steps per wavefront (0 = about 32 KiB of plane per workgroup)

@@ -939,11 +939,13 @@ __device__ __forceinline__ uint64_t shfl64u(uint64_t v, uint32_t src_lane)
            (uint32_t)__shfl((int)(uint32_t)v, (int)src_lane);
 }
 
-template <bool COMP>
-__global__ __launch_bounds__(SKH_BLOCK) void k_reverse_flat(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
-                                                            const uint64_t* __restrict__ offs, uint64_t total,
-                                                            uint64_t nrec, Table256 lut, uint32_t steps,
-                                                            BatchHint* __restrict__ hint, int use_hint)
+// INPLACE: in == out.  A step reads and writes the bytes of its own records only, and all its loads have landed
+// in the stage before its first store, so the staged steps are the same; a step that does not fit the stage
+// reverses its records by window pairs, and records beyond SKH_LONG_T are left whole to k_reverse_inplace_long.
+template <bool COMP, bool INPLACE>
+__device__ __forceinline__ void reverse_flat(const uint8_t* in, uint8_t* out, const uint64_t* __restrict__ offs, uint64_t total,
+                                             uint64_t nrec, const Table256& lut, uint32_t steps, BatchHint* __restrict__ hint,
+                                             int use_hint)
 {
     __shared__ uint8_t s_lut[256];
     __shared__ __attribute__((aligned(16))) uint8_t s_stage[SKH_BLOCK / 64][RF_STAGE + 32];
@@ -985,8 +987,13 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_reverse_flat(const uint8_t* __res
                     // k_reverse_tiles writes the chunks that end inside the record: the bytes of its last, partial
                     // chunk are written here
                     if (lane == 0) atomicAdd(&hint->n_long, 1u);
+                    if (INPLACE) continue;
                     const uint64_t x = (e & ~15ull) + lane;
                     if (x < e) { const uint8_t c = in[s + (e - 1 - x)]; out[x] = COMP ? s_lut[c] : c; }
+                    continue;
+                }
+                if (INPLACE) {
+                    reverse_record_inplace<COMP>(out, s, e, lane, 64, s_lut);
                     continue;
                 }
                 const uint32_t len = (uint32_t)(e - s);
@@ -1090,6 +1097,23 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_reverse_flat(const uint8_t* __res
         if (c_hi < nbytes && (c_hi != 0 || !head) && lane < nbytes - c_hi) out[a0 + c_hi + lane] = stage[c_hi + lane];
         wave_lds_handover();
     }
+}
+
+template <bool COMP>
+__global__ __launch_bounds__(SKH_BLOCK) void k_reverse_flat(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                            const uint64_t* __restrict__ offs, uint64_t total,
+                                                            uint64_t nrec, Table256 lut, uint32_t steps,
+                                                            BatchHint* __restrict__ hint, int use_hint)
+{
+    reverse_flat<COMP, false>(in, out, offs, total, nrec, lut, steps, hint, use_hint);
+}
+
+template <bool COMP>
+__global__ __launch_bounds__(SKH_BLOCK) void k_reverse_flat_inplace(uint8_t* plane, const uint64_t* __restrict__ offs,
+                                                                    uint64_t total, uint64_t nrec, Table256 lut,
+                                                                    uint32_t steps, BatchHint* __restrict__ hint, int use_hint)
+{
+    reverse_flat<COMP, true>(plane, plane, offs, total, nrec, lut, steps, hint, use_hint);
 }
 
 template <bool COMP, bool FASTQ>
@@ -2135,7 +2159,15 @@ template <bool COMP>
 static hipError_t launch_reverse_inplace_t(const LaunchCfg& cfg, uint8_t* plane, const uint64_t* offs, uint64_t nrec,
                                            uint64_t total, const Table256& lut, BatchHint* hint, hipStream_t st)
 {
-    if (cfg.staged) {
+    if (cfg.flat_inplace) {
+        const uint32_t steps = cfg.flat_steps ? cfg.flat_steps : 2;
+        const uint32_t R = flat_records_per_step(nrec ? total / nrec : 0);
+        const uint64_t nsteps = (nrec + R - 1) / R, per_block = (uint64_t)steps * (SKH_BLOCK / 64);
+        const uint64_t g1 = (nsteps + per_block - 1) / per_block;
+        if (g1 > 0x7fffffffull) return hipErrorInvalidValue;
+        if (g1) hipLaunchKernelGGL((k_reverse_flat_inplace<COMP>), dim3((uint32_t)g1), dim3(SKH_BLOCK), 0, st, plane, offs, total,
+                                   nrec, lut, steps, hint, cfg.use_hint);
+    } else if (cfg.staged) {
         // short reads: the LDS-staged kernel with one plane (aligned row loads and stores)
         const uint32_t steps = cfg.staged_steps ? cfg.staged_steps : 2;
         const uint64_t per_block = (uint64_t)steps * (SKH_BLOCK >> cfg.logG);

@@ -140,12 +140,12 @@ def run_revcomp_inplace(lib, ctx, seq, qual, offs, lut, do_reverse):
     return d_seq.cpu().numpy(), d_qual.cpu().numpy() if qual is not None else None
 
 
-# in place: the LDS-staged kernel with one plane (short reads) or window pairs per lane; both for every case
-@pytest.fixture(scope="module", params=["auto", "staged", "pairs"])
+# in place: the LDS-staged kernel with one plane (short reads), window pairs per lane, or the flat kernel; all for every case
+@pytest.fixture(scope="module", params=["auto", "staged", "pairs", "flat"])
 def ctx_default(lib, request):
     old = os.environ.get("SKH_STAGED")
     if request.param != "auto":
-        os.environ["SKH_STAGED"] = "1" if request.param == "staged" else "0"
+        os.environ["SKH_STAGED"] = {"staged": "1", "pairs": "0", "flat": "2"}[request.param]
     c = lib.init(0)
     os.environ.pop("SKH_STAGED", None)
     if old is not None:
@@ -240,6 +240,9 @@ def test_flat_kernel_step_shapes(lib, ora, monkeypatch):
                 got_s, got_q = run_revcomp(lib, c, seq, qual, offs, lut, True)
                 assert np.array_equal(got_s[:total], want_s[:total]), (name, steps)
                 assert np.array_equal(got_q[:total], want_q[:total]), (name, steps)
+                got_s, got_q = run_revcomp_inplace(lib, c, seq, qual, offs, lut, True)
+                assert np.array_equal(got_s[:total], want_s[:total]), (name, steps, "in place")
+                assert np.array_equal(got_q[:total], want_q[:total]), (name, steps, "in place")
         finally:
             lib.skh_destroy(c)
 
