@@ -435,3 +435,45 @@ def test_round_trip_at_bench_size(lib, ctx):
     c1, c2 = c1.view(nrec, 4), c2.view(nrec, 4)
     assert torch.equal(c1[:, [3, 2, 1, 0]], c2)           # A<->T, C<->G
     assert int(c1.sum()) == int((seq != ord("N")).sum())
+
+
+@pytest.mark.parametrize("shape", ["reads100", "trimmed30_151", "heavy_tail", "kilobases"])
+def test_round_trip_at_scale_ragged(lib, ctx_default, shape):
+    # Size-independent properties on batches of 0.2-0.5 Gbases whose lengths are not the bench's 150: reversing and
+    # complementing twice is the identity (out of place and in place), the first pass equals the in-place pass, and
+    # the per-record counts of the result are the complement-swapped counts of the input.  First and last records
+    # against numpy.
+    import torch
+    rng = np.random.default_rng(17)
+    lengths = {"reads100": np.full(3_000_000, 100), "trimmed30_151": rng.integers(30, 152, 3_000_000),
+               "heavy_tail": np.clip(np.exp(rng.normal(np.log(120), 0.7, 2_000_000)), 1, 40000).astype(np.int64),
+               "kilobases": rng.integers(500, 2500, 300_000)}[shape].astype(np.int64)
+    offs_h = np.zeros(len(lengths) + 1, np.int64); np.cumsum(lengths, out=offs_h[1:])
+    nrec, total = len(lengths), int(offs_h[-1])
+    g = torch.Generator(device="cuda:0"); g.manual_seed(3)
+    letters = torch.tensor(list(b"ACGTNacgtn"), dtype=torch.uint8, device="cuda:0")
+    seq = torch.zeros((total + 15) & ~15, dtype=torch.uint8, device="cuda:0")
+    seq[:total] = letters[torch.randint(0, len(letters), (total,), generator=g, device="cuda:0")]
+    offs = torch.from_numpy(offs_h).to("cuda:0")
+    a, b2, w = torch.empty_like(seq), torch.empty_like(seq), seq.clone()
+    lut = lib.pair_table(1)
+    torch.cuda.synchronize()
+    lib.check(lib.skh_revcomp_dev(ctx_default, ptr(seq), ptr(a), ptr(offs), nrec, total, lut, 1, None))
+    lib.check(lib.skh_revcomp_dev(ctx_default, ptr(a), ptr(b2), ptr(offs), nrec, total, lut, 1, None))
+    lib.check(lib.skh_revcomp_inplace_dev(ctx_default, ptr(w), None, ptr(offs), nrec, total, lut, 1, None))
+    cls = lib.class_table(["Aa", "Cc", "Gg", "Tt"])
+    c1 = torch.empty(nrec * 4, dtype=torch.int64, device="cuda:0"); c2 = torch.empty_like(c1)
+    lib.check(lib.skh_count_dev(ctx_default, ptr(seq), ptr(offs), nrec, total, cls, 4, ptr(c1), None))
+    lib.check(lib.skh_count_dev(ctx_default, ptr(a), ptr(offs), nrec, total, cls, 4, ptr(c2), None))
+    lib.check(lib.skh_sync(ctx_default))
+    assert torch.equal(seq[:total], b2[:total])
+    assert torch.equal(a[:total], w[:total])
+    lib.check(lib.skh_revcomp_inplace_dev(ctx_default, ptr(w), None, ptr(offs), nrec, total, lut, 1, None))
+    lib.check(lib.skh_sync(ctx_default))
+    assert torch.equal(seq[:total], w[:total])
+    c1, c2 = c1.view(nrec, 4), c2.view(nrec, 4)
+    assert torch.equal(c1[:, [3, 2, 1, 0]], c2)           # A<->T, C<->G
+    lut_np = np.frombuffer(bytes(lut), np.uint8)
+    for r in (0, 1, nrec // 2, nrec - 2, nrec - 1):
+        s, e = int(offs_h[r]), int(offs_h[r + 1])
+        assert np.array_equal(a[s:e].cpu().numpy(), lut_np[seq[s:e].cpu().numpy()[::-1]]), r
