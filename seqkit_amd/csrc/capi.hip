@@ -108,10 +108,12 @@ skh::LaunchCfg cfg_for(const skh_ctx* ctx, uint64_t nrec, uint64_t total)
     // lengths (57.5 / 61), whose records beyond the stage it writes straight to global memory.
     c.flat = ctx->staged >= 0 ? (ctx->staged == 2) : (mean_len < 128 || (mean_len >= 192 && mean_len < 3000));
     c.flat_steps = ctx->staged_steps;
-    // in place the flat kernel is ahead or level at every mean length below 3000 (% of HBM peak against the staged /
+    // in place the flat kernel is ahead or level at every mean length (% of HBM peak against the staged /
     // window-pair kernels: 100 bases 60 / 51, 150: 59 / 58, 250: 61.5 / 59, 30-151: 48 / 40, 500 +- 100: 60 / 46,
-    // 1000 +- 200: 61 / 50, hairpin-like lengths 47 / 48)
-    c.flat_inplace = ctx->staged >= 0 ? (ctx->staged == 2) : (mean_len < 3000);
+    // 1000 +- 200: 61 / 50, 4000 +- 800: 59 / 57, 6000 +- 1200: 63 / 58, 10000 +- 2000: 64 / 59, nanopore-like
+    // lengths 59 / 56, hairpin-like lengths 47 / 48): its steps that do not fit the stage reverse by window pairs
+    // with the whole wavefront on one record
+    c.flat_inplace = ctx->staged >= 0 ? (ctx->staged == 2) : 1;
     // staged reverse kernel, steps per wavefront (SKH_STAGED_STEPS overrides).  Measured on batches of
     // 5-10 M records: 150-base reads fastest with 2; 250-base reads 58 -> 63 % of HBM peak with 3;
     // reads of about 100 bases and ragged 30-151-base reads gain 4-5 points with 6, where fewer of

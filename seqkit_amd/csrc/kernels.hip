@@ -1001,11 +1001,26 @@ __device__ __forceinline__ void reverse_flat(const uint8_t* in, uint8_t* out, co
                     if (lane < len) { const uint8_t c = in[e - 1 - lane]; out[s + lane] = COMP ? s_lut[c] : c; }
                     continue;
                 }
-                for (uint32_t p = lane * 16; p < len; p += 1024) {
-                    const uint32_t t = p + 16 <= len ? p : len - 16;
-                    uint4 v = reverse16(ldu16(in + s + (len - t - 16)));
-                    if (COMP) v = map16(v, s_lut);
-                    __builtin_memcpy(out + s + t, &v, 16);
+                // aligned 16-byte chunks of the output (the bytes before the first whole chunk go one per lane, the
+                // end of the record as its last 16 bytes once more), the loads of four rounds ahead of the stores
+                const uint32_t head = (uint32_t)(-s) & 15u;
+                if (lane < head) { const uint8_t c = in[e - 1 - lane]; out[s + lane] = COMP ? s_lut[c] : c; }      // head < 16 <= len
+                constexpr int FU = 4;
+                for (uint32_t pb = head + lane * 16; pb < len; pb += 1024 * FU) {
+                    uint4 v[FU];
+#pragma unroll
+                    for (int u = 0; u < FU; u++) {
+                        const uint32_t p = pb + 1024 * u, t = p + 16 <= len ? p : len - 16;
+                        v[u] = p < len ? ldu16(in + s + (len - t - 16)) : make_uint4(0, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int u = 0; u < FU; u++) {
+                        const uint32_t p = pb + 1024 * u, t = p + 16 <= len ? p : len - 16;
+                        if (p >= len) continue;
+                        uint4 w = reverse16(v[u]);
+                        if (COMP) w = map16(w, s_lut);
+                        __builtin_memcpy(out + s + t, &w, 16);
+                    }
                 }
             }
             continue;
