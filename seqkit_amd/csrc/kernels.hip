@@ -963,10 +963,17 @@ __device__ __forceinline__ void reverse_flat(const uint8_t* in, uint8_t* out, co
     uint32_t R = flat_records_per_step(mean_len);
     if (use_hint) {
         const uint32_t mean_short = __builtin_amdgcn_readfirstlane(hint->mean_short);
-        if (mean_short != ~0u && flat_records_per_step(mean_short) > R) { R = flat_records_per_step(mean_short); mean_len = mean_short; }
+        // (only when it is well below the batch mean: it comes from a sample, and records per step chosen a few per
+        // cent too high make steps overflow the stage)
+        if (mean_short != ~0u && 5ull * mean_short < 4 * mean_len && flat_records_per_step(mean_short) > R) {
+            R = flat_records_per_step(mean_short);
+            mean_len = mean_short;
+        }
     }
     const uint64_t nsteps = (nrec + R - 1) / R;
-    const uint32_t pf_cap = (uint32_t)((2 * mean_len + 15) >> 4) + 1;
+    // (twice the mean length; four times for short reads, where one record in a hundred of a log-normal batch is
+    // beyond twice the mean and every such record costs its step a memory round trip of its own)
+    const uint32_t pf_cap = (uint32_t)(((mean_len < 256 ? 4 : 2) * mean_len + 15) >> 4) + 1;
     // workgroup b serves the steps * NWAVE consecutive steps from b * steps * NWAVE on, its wavefronts interleaved
     const uint64_t step_first = (uint64_t)blockIdx.x * steps * NWAVE + wave;
     const uint64_t step_stop = (uint64_t)(blockIdx.x + 1) * steps * NWAVE;
@@ -1030,8 +1037,8 @@ __device__ __forceinline__ void reverse_flat(const uint8_t* in, uint8_t* out, co
         uint32_t PF = pieces;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)PF, d); PF = t > PF ? t : PF; }
-        // (a few records far longer than the rest would leave most slots empty: slots for twice the mean length,
-        // what a record has beyond them is copied after the slots)
+        // (a few records far longer than the rest would leave most slots empty: slots for a multiple of the mean
+        // length, what a record has beyond them is copied after the slots)
         PF = PF < pf_cap ? PF : pf_cap;
         // Records of unequal lengths would leave many of the cnt * PF slots empty: then every record gets as many
         // slots as it has pieces (at most PF), and a byte table in LDS, filled by the records' own lanes, says
