@@ -14,7 +14,7 @@ set -e
 mode=${1:-reads}
 mkdir -p gpurun_out
 DRV=./seqkit_amd/seqkit-hip; ORA=./oracle/seqkit_oracle
-L=150
+L=${L:-150}
 NREC=${NREC:-10000000}
 BASES=$((NREC * L))
 t() { local s=$(date +%s.%N); "$@" > /dev/null; local e=$(date +%s.%N); echo "$s $e" | awk -v b=$BASES '{printf "%8.3f s  %8.3f Gbases/s", $2-$1, b/($2-$1)/1e9}'; }
