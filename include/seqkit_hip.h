@@ -523,6 +523,46 @@ int skh_count_submit(skh_ctx *ctx, skh_batch *b, uint64_t nrec, const uint8_t cl
                      uint32_t nclass, uint64_t *counts);
 int skh_batch_wait(skh_batch *b);
 
+/* ---- one pinned batch, several GPUs at once ---------------------------------------------
+ * The product form of the sharding rules above, for a caller that holds ONE batch in pinned host
+ * memory (a skh_batch filled by its reader) and several GPUs: what the reference does with -j inside one
+ * long record (seq.ComplementThreads = config.Threads, seqkit/cmd/seq.go:88, README.md:285-295) and with
+ * its per-file accumulators (stat.go:106-125), done across GPUs.  skh_multi_init starts one worker thread
+ * per context.  Every call cuts the batch into one share of about equal byte volume per context
+ * (skh_split_plane), each worker uploads its share in chunks on two streams of its GPU, runs the
+ * single-GPU kernels on it and downloads the results to the share's own place in the batch, all
+ * workers at once; nothing moves between GPUs.  The batch may belong to any context (its host planes
+ * are pinned for every GPU); its contents are as after the single-GPU call of the same name:
+ *   skh_revcomp_multi  in place in the batch; the pieces of a record that was cut land at the mirrored
+ *                      places [L-b, L-a) of that record once every share has been read;
+ *   skh_count_multi    counts[nrec * nclass]; a record that was cut gets the sum of its pieces' rows;
+ *   skh_stats_multi    per-share totals (a record counts where it starts) merged by the path's one
+ *                      collective, skh_stats_allreduce over a communicator of the contexts, into *inout.
+ * skh_split_plane: cuts[0..nparts] are byte positions of the plane; a cut lies at the record boundary
+ * nearest to k/nparts of the bytes when that boundary is within 1/16 of a share of it
+ * (skh_split_by_bytes' rule), else inside the record at a multiple of 16 bytes from the record's start
+ * (skh_split_record's rule).  skh_multi_shares reports what every context did in the last call
+ * (n = skh_multi_size entries).  Calls on one skh_multi must not overlap. */
+typedef struct skh_multi skh_multi;
+typedef struct skh_share_info {
+    uint64_t first_byte, last_byte;   /* the share: bytes [first_byte, last_byte) of the plane          */
+    uint64_t first_record, nrecords;  /* records it touches, the cut ones at either end included        */
+    uint64_t head_cut, tail_cut;      /* bytes of its first / last record that lie outside the share    */
+    uint32_t chunks, reserved;        /* upload-kernel-download rounds the share was worked in          */
+    double   seconds;                 /* wall time of the share on its worker thread                    */
+} skh_share_info;
+int  skh_split_plane(const uint64_t *offsets, uint64_t nrec, int nparts, uint64_t *cuts);
+int  skh_multi_init(skh_ctx *const *ctxs, int n, skh_multi **out);
+void skh_multi_destroy(skh_multi *m);
+int  skh_multi_size(const skh_multi *m);
+int  skh_revcomp_multi(skh_multi *m, skh_batch *b, uint64_t nrec, const uint8_t *lut, int do_reverse,
+                       int reverse_qual);
+int  skh_count_multi(skh_multi *m, skh_batch *b, uint64_t nrec, const uint8_t class_of[256], uint32_t nclass,
+                     uint64_t *counts);
+int  skh_stats_multi(skh_multi *m, skh_batch *b, uint64_t nrec, const uint8_t is_gap[256],
+                     skh_stats_partial *inout);
+int  skh_multi_shares(const skh_multi *m, skh_share_info *info);
+
 #ifdef __cplusplus
 }
 #endif

@@ -10,7 +10,7 @@ ROOT = os.path.dirname(PKG)
 LIB = os.path.join(PKG, "libseqkit_hip.so")
 CLI = os.path.join(PKG, "seqkit-hip")
 
-LIB_SRCS = [os.path.join(PKG, "csrc", f) for f in ("capi.hip", "kernels.hip", "parse.hip", "format.hip", "slices.hip", "gaps.hip", "multi.hip")]
+LIB_SRCS = [os.path.join(PKG, "csrc", f) for f in ("capi.hip", "kernels.hip", "parse.hip", "format.hip", "slices.hip", "gaps.hip", "multi.hip", "shares.hip")]
 LIB_DEPS = LIB_SRCS + [os.path.join(PKG, "csrc", "kernels.h"), os.path.join(PKG, "csrc", "device_util.h"), os.path.join(PKG, "csrc", "ctx.h"), os.path.join(ROOT, "include", "seqkit_hip.h")]
 CLI_SRCS = [os.path.join(PKG, "host", f) for f in ("main.cpp", "fastx_reader.cpp", "commands.cpp", "format.cpp")]
 CLI_DEPS = CLI_SRCS + [os.path.join(PKG, "host", "host.h"), os.path.join(ROOT, "include", "seqkit_hip.h")]

@@ -56,6 +56,12 @@ class ValidateResult(C.Structure):
     _fields_ = [("record", C.c_uint64), ("offset", C.c_uint64), ("letter", C.c_uint32), ("found", C.c_uint32)]
 
 
+class ShareInfo(C.Structure):
+    _fields_ = [("first_byte", C.c_uint64), ("last_byte", C.c_uint64), ("first_record", C.c_uint64),
+                ("nrecords", C.c_uint64), ("head_cut", C.c_uint64), ("tail_cut", C.c_uint64),
+                ("chunks", C.c_uint32), ("reserved", C.c_uint32), ("seconds", C.c_double)]
+
+
 class FormatResult(C.Structure):
     _fields_ = [("out_bytes", C.c_uint64), ("status", C.c_uint32), ("reserved", C.c_uint32)]
 
@@ -135,6 +141,14 @@ SYMBOLS = {
     "skh_comm_local_ranks": (C.c_int, [vp]),
     "skh_stats_allreduce": (C.c_int, [vp, C.POINTER(StatsPartial)]),
     "skh_stats_allreduce_dev": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp)]),
+    "skh_split_plane": (C.c_int, [u64p, C.c_uint64, C.c_int, u64p]),
+    "skh_multi_init": (C.c_int, [C.POINTER(vp), C.c_int, C.POINTER(vp)]),
+    "skh_multi_destroy": (None, [vp]),
+    "skh_multi_size": (C.c_int, [vp]),
+    "skh_revcomp_multi": (C.c_int, [vp, vp, C.c_uint64, u8p, C.c_int, C.c_int]),
+    "skh_count_multi": (C.c_int, [vp, vp, C.c_uint64, u8p, C.c_uint32, u64p]),
+    "skh_stats_multi": (C.c_int, [vp, vp, C.c_uint64, u8p, C.POINTER(StatsPartial)]),
+    "skh_multi_shares": (C.c_int, [vp, C.POINTER(ShareInfo)]),
     "skh_batch_alloc": (C.c_int, [vp, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(vp)]),
     "skh_batch_free": (None, [vp]),
     "skh_batch_seq": (vp, [vp]),

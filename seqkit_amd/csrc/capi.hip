@@ -66,26 +66,8 @@ static __device__ __align__(256) unsigned long long scratch[skh::STATS_SLOT_WORD
 
 int skh::set_error(int code, const char* fmt, const char* a, const char* b) { return fail(code, fmt, a, b); }
 
-struct skh_batch {
-    skh_ctx* ctx = nullptr;
-    uint64_t max_bytes = 0, max_records = 0;
-    bool with_qual = false;
-    uint8_t *h_seq = nullptr, *h_qual = nullptr;
-    uint64_t* h_offs = nullptr;
-    uint8_t *d_seq = nullptr, *d_seq_out = nullptr, *d_qual = nullptr, *d_qual_out = nullptr;
-    uint64_t* d_offs = nullptr;
-    uint64_t *d_counts = nullptr, *h_counts = nullptr;
-    skh::StatsPartial *d_stats = nullptr, *h_stats = nullptr;
-    hipStream_t stream = nullptr;
-    // completion of a submitted operation
-    uint64_t* user_counts = nullptr;
-    uint64_t n_counts = 0;
-    bool pending = false;
-};
 
-namespace {
-
-skh::LaunchCfg cfg_for(const skh_ctx* ctx, uint64_t nrec, uint64_t total)
+skh::LaunchCfg skh::cfg_for(const skh_ctx* ctx, uint64_t nrec, uint64_t total)
 {
     skh::LaunchCfg c;
     c.max_grid = ctx->max_grid;
@@ -139,7 +121,7 @@ skh::LaunchCfg cfg_for(const skh_ctx* ctx, uint64_t nrec, uint64_t total)
 // when they are destroyed (slot_release); with more than N_SLOTS caller streams alive at once the
 // device is drained (nothing in flight can then share a slot with a later launch) and the table
 // starts again.
-int slot_for(skh_ctx* ctx, hipStream_t st, uint32_t* slot)
+int skh::slot_for(skh_ctx* ctx, hipStream_t st, uint32_t* slot)
 {
     std::lock_guard<std::mutex> lock(ctx->slot_mu);
     auto it = ctx->slot_of.find(st);
@@ -158,11 +140,17 @@ int slot_for(skh_ctx* ctx, hipStream_t st, uint32_t* slot)
     return SKH_OK;
 }
 
-void slot_release(skh_ctx* ctx, hipStream_t st)
+void skh::slot_release(skh_ctx* ctx, hipStream_t st)
 {
     std::lock_guard<std::mutex> lock(ctx->slot_mu);
     ctx->slot_of.erase(st);
 }
+
+namespace {
+
+using skh::cfg_for;
+using skh::slot_for;
+using skh::slot_release;
 
 int check_plane_args(const void* a, const void* offs, uint64_t nrec, uint64_t total)
 {
@@ -727,19 +715,16 @@ int skh_batch_alloc(skh_ctx* ctx, uint64_t max_bytes, uint64_t max_records, int 
     b->max_records = max_records ? max_records : 1;
     b->with_qual = with_qual != 0;
     const size_t offs_bytes = (b->max_records + 1) * sizeof(uint64_t);
+    // host planes only: they are pinned for every GPU of the process (a batch may be handed to
+    // skh_*_multi, whose contexts copy their shares straight out of these buffers); the device
+    // planes of the batch's own context are allocated by its first single-GPU call
     hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&b->h_seq), b->max_bytes, hipHostMallocDefault);
-    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&b->h_offs), offs_bytes, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&b->h_seq), b->max_bytes, hipHostMallocPortable);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&b->h_offs), offs_bytes, hipHostMallocPortable);
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&b->h_stats), sizeof(skh::StatsPartial), hipHostMallocDefault);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&b->d_seq), b->max_bytes);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&b->d_seq_out), b->max_bytes);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&b->d_offs), offs_bytes);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&b->d_stats), sizeof(skh::StatsPartial));
-    if (e == hipSuccess && b->with_qual) {
-        e = hipHostMalloc(reinterpret_cast<void**>(&b->h_qual), b->max_bytes, hipHostMallocDefault);
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&b->d_qual), b->max_bytes);
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&b->d_qual_out), b->max_bytes);
-    }
+    if (e == hipSuccess && b->with_qual)
+        e = hipHostMalloc(reinterpret_cast<void**>(&b->h_qual), b->max_bytes, hipHostMallocPortable);
     if (e != hipSuccess) {
         skh_batch_free(b);
         return hip_fail(e, "skh_batch_alloc");
@@ -791,6 +776,15 @@ static int batch_total(const skh_batch* b, uint64_t nrec, uint64_t* total)
 static int upload(skh_batch* b, uint64_t nrec, uint64_t total, bool qual)
 {
     HIP_TRY(hipSetDevice(b->ctx->device));
+    if (!b->d_seq) {
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&b->d_seq), b->max_bytes));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&b->d_seq_out), b->max_bytes));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&b->d_offs), (b->max_records + 1) * sizeof(uint64_t)));
+    }
+    if (b->with_qual && !b->d_qual) {
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&b->d_qual), b->max_bytes));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&b->d_qual_out), b->max_bytes));
+    }
     HIP_TRY(hipMemcpyAsync(b->d_offs, b->h_offs, (nrec + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, b->stream));
     const uint64_t padded = skh_padded_size(total);
     if (padded) HIP_TRY(hipMemcpyAsync(b->d_seq, b->h_seq, padded, hipMemcpyHostToDevice, b->stream));

@@ -30,7 +30,30 @@ struct skh_ctx {
     uint32_t stats_steps = 0;
 };
 
+struct skh_batch {
+    skh_ctx* ctx = nullptr;
+    uint64_t max_bytes = 0, max_records = 0;
+    bool with_qual = false;
+    uint8_t *h_seq = nullptr, *h_qual = nullptr;
+    uint64_t* h_offs = nullptr;
+    uint8_t *d_seq = nullptr, *d_seq_out = nullptr, *d_qual = nullptr, *d_qual_out = nullptr;
+    uint64_t* d_offs = nullptr;
+    uint64_t *d_counts = nullptr, *h_counts = nullptr;
+    skh::StatsPartial *d_stats = nullptr, *h_stats = nullptr;
+    hipStream_t stream = nullptr;
+    // completion of a submitted operation
+    uint64_t* user_counts = nullptr;
+    uint64_t n_counts = 0;
+    bool pending = false;
+};
+
 namespace skh {
 // sets the calling thread's skh_last_error() text and returns `code` (defined in capi.hip)
 int set_error(int code, const char* fmt, const char* a = "", const char* b = "");
+// launch parameters for a batch of nrec records and `total` bytes on this context (capi.hip)
+LaunchCfg cfg_for(const skh_ctx* ctx, uint64_t nrec, uint64_t total);
+// the launch-scratch slot of stream `st` on this context; the library's own streams give theirs back
+// with slot_release before they are destroyed (capi.hip)
+int slot_for(skh_ctx* ctx, hipStream_t st, uint32_t* slot);
+void slot_release(skh_ctx* ctx, hipStream_t st);
 }

@@ -40,6 +40,50 @@ def split_record(length, nparts, align=16):
     return [(cuts[i], cuts[i + 1], length - cuts[i + 1]) for i in range(nparts)]
 
 
+def split_plane(offsets, nparts):
+    """Byte positions cuts[0..nparts] that cut the plane of a batch into shares of about equal volume
+    (the rule of the library's skh_split_plane): a cut lies at the record boundary nearest to k/nparts
+    of the bytes when that boundary is within 1/16 of a share of it, else inside the record at a multiple
+    of 16 bytes from the record's start."""
+    offsets = np.asarray(offsets, dtype=np.uint64)
+    nrec = len(offsets) - 1
+    total = int(offsets[-1])
+    tol = total // nparts // 16
+    cuts = [0]
+    for k in range(1, nparts):
+        target = total * k // nparts
+        r = int(np.searchsorted(offsets, np.uint64(target), side="left"))      # offsets[r] >= target
+        cut = int(offsets[min(r, nrec)])
+        if cut != target:
+            s, e = int(offsets[r - 1]), int(offsets[r])
+            if e - target <= tol and e - target <= target - s:
+                cut = e
+            elif target - s <= tol:
+                cut = s
+            else:
+                cut = s + (target - s) // 16 * 16
+        cuts.append(max(cut, cuts[-1]))
+    cuts.append(total)
+    return cuts
+
+
+def pieces_of_share(offsets, b0, b1):
+    """The pieces [(record, a, b)] that tile plane bytes [b0, b1): record-relative slices, whole records
+    as (r, 0, L).  Empty records are not listed."""
+    offsets = np.asarray(offsets, dtype=np.uint64)
+    out = []
+    if b1 <= b0:
+        return out
+    r = int(np.searchsorted(offsets, np.uint64(b0), side="right")) - 1
+    while r < len(offsets) - 1 and int(offsets[r]) < b1:
+        s, e = int(offsets[r]), int(offsets[r + 1])
+        a, b = max(s, b0), min(e, b1)
+        if b > a:
+            out.append((r, a - s, b - s))
+        r += 1
+    return out
+
+
 def plan_pieces(lengths, nparts, align=16):
     """Byte-volume sharding with cuts inside records: rank k gets the pieces [(record, a, b)] that
     cover bytes [k * total / nparts, (k+1) * total / nparts) of the batch, a cut inside a record moved
