@@ -14,12 +14,15 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <array>
 #include <chrono>
 #include <atomic>
 #include <climits>
 #include <condition_variable>
 #include <cstring>
 #include <deque>
+#include <functional>
+#include <future>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -39,6 +42,7 @@ struct Ctx {
     skh_ctx* c = nullptr;
     std::vector<skh_ctx*> all;
     skh_comm* comm = nullptr;                 // made on first use (stats over several GPUs)
+    skh_multi* multi = nullptr;               // several GPUs: pinned batches are cut over all of them (skh_*_multi)
     int init(const GlobalOpts& g)
     {
         for (int d : g.devices) {
@@ -47,11 +51,25 @@ struct Ctx {
             all.push_back(x);
         }
         c = all[0];
+        if (all.size() > 1 && skh_multi_init(all.data(), (int)all.size(), &multi) != SKH_OK) return -1;
         return 0;
+    }
+    // SKH_SHARES=1: what every GPU did in the last skh_*_multi call, on stderr
+    void report_shares(const char* what) const
+    {
+        if (!multi || !getenv("SKH_SHARES")) return;
+        std::vector<skh_share_info> info((size_t)skh_multi_size(multi));
+        if (skh_multi_shares(multi, info.data()) != SKH_OK) return;
+        for (size_t k = 0; k < info.size(); k++)
+            fprintf(stderr, "[shares] %s: context %zu bytes [%llu, %llu) records %llu..%llu head_cut %llu tail_cut %llu chunks %u\n", what, k,
+                    (unsigned long long)info[k].first_byte, (unsigned long long)info[k].last_byte,
+                    (unsigned long long)info[k].first_record, (unsigned long long)(info[k].first_record + info[k].nrecords),
+                    (unsigned long long)info[k].head_cut, (unsigned long long)info[k].tail_cut, info[k].chunks);
     }
     ~Ctx()
     {
         drop_cached_blocks();
+        if (multi) skh_multi_destroy(multi);
         if (comm) skh_comm_destroy(comm);
         for (skh_ctx* x : all) skh_destroy(x);
     }
@@ -80,6 +98,61 @@ struct PhaseTimer {
     explicit PhaseTimer(int k_) : k(k_), t0(g_phases.on ? Phases::now() : 0) {}
     ~PhaseTimer() { if (g_phases.on) g_phases.t[k] += Phases::now() - t0; }
 };
+
+// GPU work on a pinned batch, in flight: with one GPU it is a skh_*_submit on the batch's own stream,
+// with several a skh_*_multi call (synchronous: all GPUs work on the one batch) on a helper thread,
+// so the host can print the batch before while it runs.
+struct BatchWork {
+    std::future<int> fut;
+    std::string err;
+    bool active = false;
+    template <typename F> void start(F&& call)
+    {
+        active = true;
+        fut = std::async(std::launch::async, [this, call] { const int rc = call(); if (rc != SKH_OK) err = skh_last_error(); return rc; });
+    }
+    int wait()
+    {
+        if (!active) return SKH_OK;
+        active = false;
+        return fut.get();
+    }
+    ~BatchWork() { if (active) (void)fut.get(); }
+};
+
+// A plain FASTA file whose first record is longer than a text block (a chromosome, say).  With several
+// GPUs such a file goes through pinned batches, where ONE record is cut over all GPUs (skh_*_multi);
+// as text blocks a record lives on the one GPU its block was dealt to.
+bool first_record_exceeds_block(const std::string& path, uint64_t block_bytes)
+{
+    if (path == "-") return false;
+    const int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) return false;
+    struct stat st;
+    bool yes = false;
+    if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && (uint64_t)st.st_size > block_bytes) {
+        std::vector<uint8_t> buf(block_bytes);
+        uint64_t have = 0;
+        while (have < block_bytes) {
+            const ssize_t n = pread(fd, buf.data() + have, (size_t)(block_bytes - have), (off_t)have);
+            if (n <= 0) break;
+            have += (uint64_t)n;
+        }
+        uint64_t k = 0;
+        while (k < have && (buf[k] == '\n' || buf[k] == '\r')) k++;
+        if (have == block_bytes && k < have && buf[k] == '>') {
+            yes = true;
+            for (const uint8_t* p = buf.data() + k + 1; yes;) {
+                p = static_cast<const uint8_t*>(memchr(p, '>', (size_t)(buf.data() + have - p)));
+                if (!p) break;
+                if (p[-1] == '\n') yes = false;
+                p++;
+            }
+        }
+    }
+    close(fd);
+    return yes;
+}
 
 // Reads `want` bytes at `pos` of a regular file: the stretch is cut into equal parts read with
 // pread(2) by a few threads at once (one thread copies page-cache pages at 10-25 GB/s, a PCIe
@@ -713,7 +786,7 @@ public:
     {
         State& s = *s_;
         s.ctxs = ctxs; s.path = path;
-        s.nblocks = std::max<size_t>(4, 2 * ctxs.size());
+        s.nblocks = std::max<size_t>(4, 2 * ctxs.size() + 2);       // two per GPU with their workers, two with the reader and the parser
         if (path != "-") {
             s.fd = open(path.c_str(), O_RDONLY);
             if (s.fd < 0) { s.err = "open " + path + ": no such file or directory"; return; }
@@ -806,21 +879,130 @@ private:
 void drop_cached_blocks() { BlockPipe::drop_cache(); }
 namespace {
 
+// ---- one worker thread per GPU behind a BlockPipe --------------------------------------------
+//
+// The blocks of a file are dealt to the command's GPUs in turn.  The command hands every parsed
+// block to the worker of the block's GPU, which runs the block's kernels, formats its output and
+// waits for the download, and takes the finished blocks back in file order to write them: the
+// kernels and transfers of different GPUs run side by side (what -j / runtime.GOMAXPROCS is to the
+// reference's commands, seqkit/cmd/root.go:60-64, seq.go:52), and the writes overlap all of it.
+struct BlockJob {
+    void* held = nullptr;               // the block, out of the pipe's round until release()
+    skh_text* t = nullptr;
+    skh_parse_result res;
+    int dev = 0;                        // index of its GPU in the command's device list
+    // what the step made of it
+    int rc = 0; std::string err;        // a failure of the step itself
+    const uint8_t* text = nullptr; uint64_t nbytes = 0;    // output text, in the block's pinned memory
+    std::string record_error;           // seq -v: the block ends before a record with an invalid letter
+    std::vector<uint64_t> offs;         // stats -a: the offsets of its records
+    bool done = false;
+};
+
+class BlockWorkers {
+public:
+    BlockWorkers(size_t ndev, std::function<void(BlockJob&)> step) : step_(std::move(step)), q_(ndev)
+    {
+        for (size_t d = 0; d < ndev; d++) thr_.emplace_back([this, d] { run(d); });
+    }
+    ~BlockWorkers()
+    {
+        { std::lock_guard<std::mutex> l(mu_); stop_ = true; }
+        cv_.notify_all();
+        for (auto& t : thr_) t.join();
+    }
+    BlockWorkers(const BlockWorkers&) = delete;
+    BlockWorkers& operator=(const BlockWorkers&) = delete;
+    void submit(BlockJob* j)
+    {
+        { std::lock_guard<std::mutex> l(mu_); q_[(size_t)j->dev].push_back(j); }
+        cv_.notify_all();
+    }
+    bool is_done(BlockJob* j) { std::lock_guard<std::mutex> l(mu_); return j->done; }
+    void wait(BlockJob* j)
+    {
+        PhaseTimer pt(9);
+        std::unique_lock<std::mutex> l(mu_);
+        cv_.wait(l, [&] { return j->done; });
+    }
+
+private:
+    void run(size_t d)
+    {
+        for (;;) {
+            BlockJob* j;
+            {
+                std::unique_lock<std::mutex> l(mu_);
+                cv_.wait(l, [&] { return stop_ || !q_[d].empty(); });
+                if (stop_) return;                   // what is still queued belongs to a command that gave up
+                j = q_[d].front(); q_[d].pop_front();
+            }
+            step_(*j);
+            { std::lock_guard<std::mutex> l(mu_); j->done = true; }
+            cv_.notify_all();
+        }
+    }
+    std::function<void(BlockJob&)> step_;
+    std::mutex mu_; std::condition_variable cv_;
+    std::vector<std::deque<BlockJob*>> q_;
+    std::vector<std::thread> thr_;
+    bool stop_ = false;
+};
+
+// The blocks in flight of one file, in file order: `emit` gets each finished block once, in order.
+// Returns the first non-zero result of emit (or of a step), after which nothing more is emitted.
+class OrderedBlocks {
+public:
+    OrderedBlocks(BlockPipe& tb, BlockWorkers& w, size_t limit, std::function<int(BlockJob&)> emit)
+        : tb_(tb), w_(w), limit_(limit), emit_(std::move(emit)) {}
+    // takes the pipe's current block; finished blocks at the head of the line are emitted
+    int submit(const skh_parse_result& res, bool run_here, const std::function<void(BlockJob&)>& step)
+    {
+        auto j = std::make_unique<BlockJob>();
+        j->t = tb_.block(); j->res = res; j->dev = tb_.device_index();
+        j->held = tb_.hold();
+        if (run_here) { step(*j); j->done = true; }
+        else w_.submit(j.get());
+        line_.push_back(std::move(j));
+        return drain(false);
+    }
+    int finish() { return drain(true); }
+    ~OrderedBlocks() { for (auto& j : line_) w_.wait(j.get()); }     // (the workers still own what they were handed)
+
+private:
+    int drain(bool all)
+    {
+        while (!line_.empty() && (all || line_.size() > limit_ || w_.is_done(line_.front().get()))) {
+            BlockJob& j = *line_.front();
+            w_.wait(&j);
+            int rc = j.rc ? fatal(j.err) : emit_(j);
+            tb_.release(j.held);
+            line_.pop_front();
+            if (rc) return rc;
+        }
+        return 0;
+    }
+    BlockPipe& tb_; BlockWorkers& w_; size_t limit_;
+    std::function<int(BlockJob&)> emit_;
+    std::deque<std::unique_ptr<BlockJob>> line_;
+};
+
 // Record IDs by a rule other than the default one: the name spans of the block are replaced by the ID
 // spans (the formatter then prints "names" that are the IDs).  The head lines are on the host already
 // (the block's text buffer); the expression runs here, record by record.
-int custom_ids_as_names(const GlobalOpts& g, skh_text* t, uint64_t nrec, std::vector<uint64_t>& npos, std::vector<uint32_t>& nlen)
+int custom_ids_as_names(const GlobalOpts& g, skh_text* t, uint64_t nrec, std::vector<uint64_t>& npos, std::vector<uint32_t>& nlen,
+                        std::string& err)
 {
     skh_ctx* ctx = skh_text_ctx(t);
     npos.resize(nrec); nlen.resize(nrec);
-    if (skh_text_names(ctx, t, 0, nrec, npos.data(), nlen.data()) != SKH_OK) return fatal(skh_last_error());
+    if (skh_text_names(ctx, t, 0, nrec, npos.data(), nlen.data()) != SKH_OK) { err = skh_last_error(); return -1; }
     const uint8_t* text = skh_text_buffer(t);
     for (uint64_t r = 0; r < nrec; r++) {
         uint32_t off = 0, len = 0;
         id_span(g, text + npos[r], nlen[r], &off, &len);
         npos[r] += off; nlen[r] = len;
     }
-    if (skh_text_set_names(ctx, t, 0, nrec, npos.data(), nlen.data()) != SKH_OK) return fatal(skh_last_error());
+    if (skh_text_set_names(ctx, t, 0, nrec, npos.data(), nlen.data()) != SKH_OK) { err = skh_last_error(); return -1; }
     return 0;
 }
 
@@ -838,11 +1020,10 @@ int first_record_alphabet(skh_ctx* ctx, skh_text* t, const GlobalOpts& g, int fo
 }
 
 // `seq` with parse and output formatting on the GPU (seq.go:114-280 a block at a time)
-int seq_text_path(const GlobalOpts& g, const SeqOpts& o, const std::vector<std::string>& files, const std::vector<skh_ctx*>& ctxs, Sink& out)
+int seq_text_path(const GlobalOpts& g, const SeqOpts& o, const std::vector<std::string>& files, const std::vector<skh_ctx*>& ctxs, Sink& out,
+                  bool& is_fastq, bool& check_type)      // seq.go:105-106: decided once per command, by the first printed record
 {
-    bool is_fastq = false, check_type = true;        // seq.go:105-106: decided once, by the first printed record
-    std::vector<uint64_t> offs, id_pos;
-    std::vector<uint32_t> id_len;
+    std::vector<uint64_t> offs;
     for (const std::string& file : files) {
         bool warn_once = true;                       // seq.go:118: one "already RNA / DNA" warning per file
         BlockPipe tb(ctxs, file, g.text_block_bytes);
@@ -850,51 +1031,99 @@ int seq_text_path(const GlobalOpts& g, const SeqOpts& o, const std::vector<std::
         uint8_t lut[256], valid[256], gap_pre[256];
         bool lut_ready = false, any_map = false;
         int ab = -1;                                  // the file's alphabet: -t, or guessed from its first record
-        std::string pending_error;                    // an invalid record: reported after the records before it
         skh_parse_result res;
-        // the output of a block is downloaded while the next block is worked on: `held` is the block
-        // whose text is still on its way
-        void* held = nullptr;
-        auto flush_held = [&]() -> int {
-            if (!held) return 0;
-            const uint8_t* text = nullptr;
-            uint64_t nbytes = 0;
-            {
-                PhaseTimer pt(3);
-                if (skh_text_output_wait(skh_text_ctx(BlockPipe::text_of(held)), BlockPipe::text_of(held), &text, &nbytes) != SKH_OK) return fatal(skh_last_error());
-            }
-            { PhaseTimer pt(4); out.write(text, nbytes); }
-            tb.release(held);
-            held = nullptr;
-            return 0;
+        // What a block goes through, in two steps.  The first (validation) and everything decided from the
+        // first records of a file or of the command (alphabet, tables, output layout) happen in file order
+        // on this thread until they are settled; from then on both steps of a block run on the worker of
+        // the block's GPU.
+        auto step_validate = [&](BlockJob& j) {
+            if (!o.validate || j.res.nrec == 0) return;
+            // the reader validates every record it builds; the first invalid one ends the command
+            skh_text* t = j.t;
+            skh_ctx* ctx = skh_text_ctx(t);
+            skh_validate_result vr;
+            if (skh_text_validate(ctx, t, valid, o.validate_len, &vr) != SKH_OK) { j.rc = -1; j.err = skh_last_error(); return; }
+            if (!vr.found) return;
+            uint64_t npos = 0; uint32_t nlen = 0;
+            if (skh_text_name(ctx, t, vr.record, &npos, &nlen) != SKH_OK) { j.rc = -1; j.err = skh_last_error(); return; }
+            const uint8_t* name = skh_text_buffer(t) + npos;
+            uint32_t ido = 0, idl = 0;
+            id_span(g, name, nlen, &ido, &idl);
+            j.record_error = "error when parsing seq: " + std::string((const char*)name + ido, idl) + " (invalid " +
+                             alphabet_name(ab) + " letter: " + std::string(1, (char)vr.letter) + ")";
+            if (skh_text_truncate(ctx, t, vr.record) != SKH_OK) { j.rc = -1; j.err = skh_last_error(); return; }
+            j.res.nrec = vr.record;
         };
-        auto one_block = [&]() -> int {
-            skh_text* t = tb.block();
-            skh_ctx* ctx = skh_text_ctx(t);              // the GPU this block was dealt to
-            if (res.nrec == 0) { tb.advance(res); return 0; }
+        auto step_transform = [&](BlockJob& j) {
+            if (j.rc || j.res.nrec == 0) return;
+            skh_text* t = j.t;
+            skh_ctx* ctx = skh_text_ctx(t);
+            auto failed = [&](const std::string& m) { j.rc = -1; j.err = m; };
+            if (o.complement && ((!g.quiet && ab == Protein) || ab == Unlimit)) {
+                // seq.go:190-193: one warning per record that gets as far as the complement (the condition
+                // reads `!config.Quiet && alphabet == Protein || alphabet == Unlimit`)
+                std::vector<uint64_t> lo(j.res.nrec + 1);
+                if (skh_text_offsets(ctx, t, 0, j.res.nrec + 1, lo.data()) != SKH_OK) return failed(skh_last_error());
+                for (uint64_t r = 0; r < j.res.nrec; r++) {
+                    const uint64_t len = lo[r + 1] - lo[r];
+                    if (o.min_len >= 0 && len < (uint64_t)o.min_len) continue;
+                    if (o.max_len >= 0 && len > (uint64_t)o.max_len) continue;
+                    fprintf(stderr, "[WARN] Complement does no take effect on protein/unlimit sequence\n");
+                }
+            }
+            if (o.remove_gaps) {
+                // seq.go:196-198 (the byte-wise table commutes with dropping bytes and with the reversal)
+                PhaseTimer pt(2);
+                if (skh_text_remove_gaps(ctx, t, gap_pre) != SKH_OK) return failed(skh_last_error());
+            }
+            if (o.reverse || any_map) {
+                // seq.go:187-195: ReverseInplace (bases and qualities), then ComplementInplace
+                PhaseTimer pt(2);
+                if (skh_text_revcomp(ctx, t, any_map ? lut : nullptr, o.reverse, 1) != SKH_OK) return failed(skh_last_error());
+            }
+            if (check_type) return;                  // no record has passed the length filters yet: nothing is printed
+            skh_seq_format f;
+            memset(&f, 0, sizeof f);
+            f.min_len = o.min_len; f.max_len = o.max_len;
+            f.line_width = tb.is_fastq() ? 0 : g.line_width;           // seq.go:136-138
+            f.print_name = 1; f.print_seq = 1; f.print_qual = is_fastq; f.plus_line = 1;
+            if (o.only_name && o.only_seq) {}
+            else if (o.only_name) { f.print_seq = 0; f.print_qual = 0; }
+            else if (o.only_seq) { f.print_name = 0; f.print_qual = 0; }
+            else if (o.only_qual) {
+                if (!is_fastq) return failed("FASTA format has no quality. So do not just use flag -q (--qual)");
+                f.print_name = 0; f.print_seq = 0; f.print_qual = 1; f.plus_line = 0;
+            }
+            // (a FASTA file after a FASTQ one keeps the FASTQ layout: "+" and an empty quality line,
+            // seq.go:140-149,258-276; the formatter prints that for a block without a quality plane)
+            f.only_id = o.only_id;
+            if (o.only_id && g.id_re && f.print_name) {
+                std::vector<uint64_t> id_pos;
+                std::vector<uint32_t> id_len;
+                std::string err;
+                if (custom_ids_as_names(g, t, j.res.nrec, id_pos, id_len, err)) return failed(err);
+                f.only_id = 0;
+            }
+            f.mark = is_fastq ? '@' : '>';
+            PhaseTimer pt(3);
+            if (skh_text_format_seq_submit(ctx, t, &f) != SKH_OK) return failed(skh_last_error());
+            if (skh_text_output_wait(ctx, t, &j.text, &j.nbytes) != SKH_OK) return failed(skh_last_error());
+        };
+        // what needs the file's records in order: the alphabet and the tables from the first record of the
+        // file, the output layout from the first record of the command that passes the length filters
+        auto step_in_order = [&](BlockJob& j) {
+            skh_text* t = j.t;
+            skh_ctx* ctx = skh_text_ctx(t);
+            auto failed = [&](const std::string& m) { j.rc = -1; j.err = m; };
+            if (j.res.nrec == 0) return;
             if (ab < 0 && (o.complement || o.validate || o.dna2rna || o.rna2dna)) {
                 std::string err;
                 ab = first_record_alphabet(ctx, t, g, g.alphabet, err);
-                if (ab < 0) return fatal(err);
+                if (ab < 0) return failed(err);
                 skh_valid_table(ab, valid);
             }
-            if (o.validate) {
-                // the reader validates every record it builds; the first invalid one ends the command
-                skh_validate_result vr;
-                if (skh_text_validate(ctx, t, valid, o.validate_len, &vr) != SKH_OK) return fatal(skh_last_error());
-                if (vr.found) {
-                    uint64_t npos = 0; uint32_t nlen = 0;
-                    if (skh_text_name(ctx, t, vr.record, &npos, &nlen) != SKH_OK) return fatal(skh_last_error());
-                    const uint8_t* name = skh_text_buffer(t) + npos;
-                    uint32_t ido = 0, idl = 0;
-                    id_span(g, name, nlen, &ido, &idl);
-                    pending_error = "error when parsing seq: " + std::string((const char*)name + ido, idl) + " (invalid " +
-                                    alphabet_name(ab) + " letter: " + std::string(1, (char)vr.letter) + ")";
-                    if (skh_text_truncate(ctx, t, vr.record) != SKH_OK) return fatal(skh_last_error());
-                    res.nrec = vr.record;
-                    if (res.nrec == 0) return 0;
-                }
-            }
+            step_validate(j);
+            if (j.rc || j.res.nrec == 0) return;
             if (!lut_ready) {
                 // One table for everything seq.go:190-241 does to a base: complement, then (when the
                 // sequence is printed) T -> U or U -> T, then the case.  Gaps are removed before the table
@@ -932,9 +1161,9 @@ int seq_text_path(const GlobalOpts& g, const SeqOpts& o, const std::vector<std::
             if (check_type) {
                 // the first record that passes the length filters decides how everything is printed
                 // (seq.go:140-145: looked at as the record was read)
-                offs.resize(res.nrec + 1);
-                if (skh_text_offsets(ctx, t, 0, res.nrec + 1, offs.data()) != SKH_OK) return fatal(skh_last_error());
-                for (uint64_t r = 0; r < res.nrec && check_type; r++) {
+                offs.resize(j.res.nrec + 1);
+                if (skh_text_offsets(ctx, t, 0, j.res.nrec + 1, offs.data()) != SKH_OK) return failed(skh_last_error());
+                for (uint64_t r = 0; r < j.res.nrec && check_type; r++) {
                     const uint64_t len = offs[r + 1] - offs[r];
                     if (o.min_len >= 0 && len < (uint64_t)o.min_len) continue;
                     if (o.max_len >= 0 && len > (uint64_t)o.max_len) continue;
@@ -942,65 +1171,28 @@ int seq_text_path(const GlobalOpts& g, const SeqOpts& o, const std::vector<std::
                     check_type = false;
                 }
             }
-            if (o.complement && ((!g.quiet && ab == Protein) || ab == Unlimit)) {
-                // seq.go:190-193: one warning per record that gets as far as the complement (the condition
-                // reads `!config.Quiet && alphabet == Protein || alphabet == Unlimit`)
-                offs.resize(res.nrec + 1);
-                if (skh_text_offsets(ctx, t, 0, res.nrec + 1, offs.data()) != SKH_OK) return fatal(skh_last_error());
-                for (uint64_t r = 0; r < res.nrec; r++) {
-                    const uint64_t len = offs[r + 1] - offs[r];
-                    if (o.min_len >= 0 && len < (uint64_t)o.min_len) continue;
-                    if (o.max_len >= 0 && len > (uint64_t)o.max_len) continue;
-                    fprintf(stderr, "[WARN] Complement does no take effect on protein/unlimit sequence\n");
-                }
-            }
-            if (o.remove_gaps) {
-                // seq.go:196-198 (the byte-wise table commutes with dropping bytes and with the reversal)
-                PhaseTimer pt(2);
-                if (skh_text_remove_gaps(ctx, t, gap_pre) != SKH_OK) return fatal(skh_last_error());
-            }
-            if (o.reverse || any_map) {
-                // seq.go:187-195: ReverseInplace (bases and qualities), then ComplementInplace
-                PhaseTimer pt(2);
-                if (skh_text_revcomp(ctx, t, any_map ? lut : nullptr, o.reverse, 1) != SKH_OK) return fatal(skh_last_error());
-            }
-            if (!check_type) {
-                skh_seq_format f;
-                memset(&f, 0, sizeof f);
-                f.min_len = o.min_len; f.max_len = o.max_len;
-                f.line_width = tb.is_fastq() ? 0 : g.line_width;           // seq.go:136-138
-                f.print_name = 1; f.print_seq = 1; f.print_qual = is_fastq; f.plus_line = 1;
-                if (o.only_name && o.only_seq) {}
-                else if (o.only_name) { f.print_seq = 0; f.print_qual = 0; }
-                else if (o.only_seq) { f.print_name = 0; f.print_qual = 0; }
-                else if (o.only_qual) {
-                    if (!is_fastq) return fatal("FASTA format has no quality. So do not just use flag -q (--qual)");
-                    f.print_name = 0; f.print_seq = 0; f.print_qual = 1; f.plus_line = 0;
-                }
-                // (a FASTA file after a FASTQ one keeps the FASTQ layout: "+" and an empty quality line,
-                // seq.go:140-149,258-276; the formatter prints that for a block without a quality plane)
-                f.only_id = o.only_id;
-                if (o.only_id && g.id_re && f.print_name) {
-                    if (int rc = custom_ids_as_names(g, t, res.nrec, id_pos, id_len)) return rc;
-                    f.only_id = 0;
-                }
-                f.mark = is_fastq ? '@' : '>';
-                {
-                    PhaseTimer pt(3);
-                    if (skh_text_format_seq_submit(ctx, t, &f) != SKH_OK) return fatal(skh_last_error());
-                }
-                if (int rc = flush_held()) return rc;
-                held = tb.hold();
-                return 0;
-            }
-            if (pending_error.empty()) tb.advance(res);
+            step_transform(j);
+        };
+        auto step_on_worker = [&](BlockJob& j) { step_validate(j); step_transform(j); };
+        std::string pending_error;                    // an invalid record: reported after the records before it
+        auto emit = [&](BlockJob& j) -> int {
+            if (j.nbytes) { PhaseTimer pt(4); out.write(j.text, j.nbytes); }
+            if (!j.record_error.empty()) { pending_error = j.record_error; return -1; }
             return 0;
         };
-        while (pending_error.empty() && tb.next(res)) {
-            if (int rc = one_block()) { flush_held(); return rc; }
+        {
+            BlockWorkers workers(ctxs.size(), step_on_worker);
+            OrderedBlocks line(tb, workers, 2 * ctxs.size(), emit);
+            int rc = 0;
+            while (rc == 0 && tb.next(res)) {
+                // settled: the alphabet is known (or not needed), the tables are made, the layout is decided
+                const bool settled = lut_ready && !check_type;
+                rc = line.submit(res, !settled, step_in_order);
+            }
+            if (rc == 0) rc = line.finish();
+            if (!pending_error.empty()) { out.flush(); return fatal(pending_error); }
+            if (rc) return rc;
         }
-        if (int rc = flush_held()) return rc;
-        if (!pending_error.empty()) { out.flush(); return fatal(pending_error); }
         if (!tb.error().empty()) return fatal(tb.error());
     }
     return 0;
@@ -1017,13 +1209,24 @@ int cmd_seq(const GlobalOpts& g, const SeqOpts& o, const std::vector<std::string
     if (g_phases.on) fprintf(stderr, "[timing] skh_init %.3f s\n", Phases::now() - t_init);
     Sink out(g.out_file);
     if (!out.ok()) return fatal("open " + g.out_file + ": cannot create");
-    if (!g.host_parse) return seq_text_path(g, o, files, ctx.all, out);
-    if (o.remove_gaps || o.lower_case || o.upper_case || o.dna2rna || o.rna2dna)
+    const bool text_only = o.remove_gaps || o.lower_case || o.upper_case || o.dna2rna || o.rna2dna;
+    if (g.host_parse && text_only)
         return fatal("--host-parse does not know -g, -l, -u, --dna2rna, --rna2dna (they are done on the GPU text path)");
     bool is_fastq = false, check_type = true;        // seq.go:105-106: decided once, by the first record
     TwoBatches tb;
+    BatchWork work[2];
 
     for (const std::string& file : files) {
+        // File text goes to the GPUs a block at a time.  Records are scanned and printed by the host, and
+        // only the per-record work is done on the GPUs, with --host-parse -- and, when there are several
+        // GPUs, for a file whose first record is longer than a text block: a pinned batch is cut over all
+        // GPUs, inside its records where they are long (skh_revcomp_multi), while a text block and the
+        // records in it belong to one GPU.
+        const bool batches = g.host_parse || (ctx.multi && !text_only && !g.id_re && first_record_exceeds_block(file, g.text_block_bytes));
+        if (!batches) {
+            if (int rc = seq_text_path(g, o, {file}, ctx.all, out, is_fastq, check_type)) return rc;
+            continue;
+        }
         FastxReader rd(ctx.c, file, g.alphabet, g.guess_len);
         if (!rd.ok()) return fatal(rd.error());
         uint8_t lut[256];
@@ -1064,6 +1267,13 @@ int cmd_seq(const GlobalOpts& g, const SeqOpts& o, const std::vector<std::string
             return 0;
         };
 
+        // the GPU work of batch k: one GPU = the batch's own stream, several = the helper thread of work[k]
+        auto gpu_wait = [&](int k) -> int {
+            if (!ctx.multi) return skh_batch_wait(tb.bt[k].b);
+            const int rc = work[k].wait();
+            ctx.report_shares("seq");
+            return rc;
+        };
         int cur = 0;
         bool have_prev = false;
         std::string pending_error;                    // an invalid record: reported after the records before it
@@ -1101,20 +1311,30 @@ int cmd_seq(const GlobalOpts& g, const SeqOpts& o, const std::vector<std::string
                         fprintf(stderr, "[WARN] Complement does no take effect on protein/unlimit sequence\n");
                     }
                 }
-                if (o.reverse || o.complement) {
-                    // seq.go:187-195: ReverseInplace (bases and qualities), then ComplementInplace
-                    if (skh_revcomp_submit(ctx.c, bt.b, bt.nrec, o.complement ? lut : nullptr, o.reverse, 1) != SKH_OK)
-                        return fatal(skh_last_error());
-                }
+            }
+            // with several GPUs all of them work on one batch at a time: the batch before must be back
+            // before this one goes out (it is printed while this one is on the GPUs)
+            if (have_prev && ctx.multi && gpu_wait(cur ^ 1) != SKH_OK) return fatal(work[cur ^ 1].err);
+            if (got && (o.reverse || o.complement)) {
+                // seq.go:187-195: ReverseInplace (bases and qualities), then ComplementInplace
+                if (ctx.multi) {
+                    skh_multi* m = ctx.multi; skh_batch* b = bt.b; const uint64_t n = bt.nrec;
+                    std::array<uint8_t, 256> table;
+                    memcpy(table.data(), lut, 256);
+                    const bool comp = o.complement;
+                    const int rev = o.reverse;
+                    work[cur].start([m, b, n, table, comp, rev] { return skh_revcomp_multi(m, b, n, comp ? table.data() : nullptr, rev, 1); });
+                } else if (skh_revcomp_submit(ctx.c, bt.b, bt.nrec, o.complement ? lut : nullptr, o.reverse, 1) != SKH_OK)
+                    return fatal(skh_last_error());
             }
             if (have_prev) {
                 Batch& pv = tb.bt[cur ^ 1];
-                if (skh_batch_wait(pv.b) != SKH_OK) return fatal(skh_last_error());
+                if (!ctx.multi && gpu_wait(cur ^ 1) != SKH_OK) return fatal(skh_last_error());
                 if (int rc = emit(pv)) return rc;
             }
             if (!pending_error.empty()) {
                 if (got) {
-                    if (skh_batch_wait(bt.b) != SKH_OK) return fatal(skh_last_error());
+                    if (gpu_wait(cur) != SKH_OK) return fatal(ctx.multi ? work[cur].err : std::string(skh_last_error()));
                     if (int rc = emit(bt)) return rc;
                 }
                 out.flush();
@@ -1193,76 +1413,18 @@ int cmd_fx2tab(const GlobalOpts& g, const Fx2tabOpts& o, const std::vector<std::
         for (const auto& bc : o.base) add(SKH_TAB_CONTENT, bc);
         tf.only_id = o.only_id;
     }
-    if (device_rows) {
-        std::vector<uint64_t> id_pos;
-        std::vector<uint32_t> id_len;
-        for (const std::string& file : files) {
-            BlockPipe tb(ctx.all, file, g.text_block_bytes);
-            if (!tb.ok()) return fatal(tb.error());
-            skh_parse_result res;
-            // the rows of a block are downloaded while the next block is counted: `held` is the block
-            // whose text is still on its way
-            void* held = nullptr;
-            auto flush_held = [&]() -> int {
-                if (!held) return 0;
-                const uint8_t* text = nullptr;
-                uint64_t nbytes = 0;
-                {
-                    PhaseTimer pt(3);
-                    if (skh_text_output_wait(skh_text_ctx(BlockPipe::text_of(held)), BlockPipe::text_of(held), &text, &nbytes) != SKH_OK) return fatal(skh_last_error());
-                }
-                { PhaseTimer pt(4); out.write(text, nbytes); }
-                tb.release(held);
-                held = nullptr;
-                return 0;
-            };
-            auto one_block = [&]() -> int {
-                skh_text* t = tb.block();
-                if (res.nrec == 0) { tb.advance(res); return 0; }
-                {
-                    PhaseTimer pt(2);
-                    for (size_t ps = 0; ps < npass; ps++)
-                        if (skh_text_count(skh_text_ctx(t), t, pass_table[ps].data(), pass_nclass[ps], (uint32_t)ps) != SKH_OK)
-                            return fatal(skh_last_error());
-                }
-                if (o.alphabet_col) {                          // fx2tab.go:145-147
-                    PhaseTimer pt(2);
-                    if (skh_text_letters(skh_text_ctx(t), t) != SKH_OK) return fatal(skh_last_error());
-                }
-                tf.alphabet = o.alphabet_col ? 1 : 0;
-                tf.only_id = o.only_id;
-                if (o.only_id && g.id_re) {
-                    if (int rc = custom_ids_as_names(g, t, res.nrec, id_pos, id_len)) return rc;
-                    tf.only_id = 0;
-                }
-                tf.print_seq = !o.only_name;
-                tf.print_qual = !o.only_name && tb.is_fastq();
-                {
-                    PhaseTimer pt(3);
-                    if (skh_text_format_tab_submit(skh_text_ctx(t), t, &tf) != SKH_OK) return fatal(skh_last_error());
-                }
-                if (int rc = flush_held()) return rc;
-                held = tb.hold();
-                return 0;
-            };
-            while (tb.next(res)) {
-                if (int rc = one_block()) { flush_held(); return rc; }
-            }
-            if (int rc = flush_held()) return rc;
-            if (!tb.error().empty()) return fatal(tb.error());
-        }
-        return 0;
-    }
-
     TwoBatches tb;
+    BatchWork work[2];
     std::vector<uint64_t> cnt[2];                    // per batch: nrec x letters.size(), letter-major per record
     std::vector<uint64_t> scratch;
     std::string num;
-    for (const std::string& file : files) {
+    // one file through pinned batches: records scanned and rows printed by the host, counts on the GPUs
+    auto batch_file = [&](const std::string& file) -> int {
         FastxReader rd(ctx.c, file, Auto, g.guess_len);
         if (!rd.ok()) return fatal(rd.error());
 
-        auto count_batch = [&](Batch& bt, std::vector<uint64_t>& dst) -> int {
+        // the counting passes of a batch: with several GPUs the batch is cut over all of them (skh_count_multi)
+        auto count_batch = [&](Batch& bt, std::vector<uint64_t>& dst, int k) -> int {
             const size_t nl = letters.size();
             dst.assign(bt.nrec * nl, 0);
             for (size_t ps = 0; ps < npass; ps++) {
@@ -1270,13 +1432,19 @@ int cmd_fx2tab(const GlobalOpts& g, const Fx2tabOpts& o, const std::vector<std::
                 scratch.resize(bt.nrec * nc);
                 // all but the last pass run synchronously; the last one overlaps with the host
                 if (ps + 1 < npass) {
-                    if (skh_count(ctx.c, bt.b, bt.nrec, pass_table[ps].data(), nc, scratch.data()) != SKH_OK)
-                        return fatal(skh_last_error());
+                    const int rc = ctx.multi ? skh_count_multi(ctx.multi, bt.b, bt.nrec, pass_table[ps].data(), nc, scratch.data())
+                                             : skh_count(ctx.c, bt.b, bt.nrec, pass_table[ps].data(), nc, scratch.data());
+                    if (rc != SKH_OK) return fatal(skh_last_error());
                     for (uint64_t r = 0; r < bt.nrec; r++)
                         for (uint32_t c = 0; c < nc; c++) dst[r * nl + ps * SKH_MAX_CLASSES + c] = scratch[r * nc + c];
                 } else {
                     bt.counts.resize(bt.nrec * nc);
-                    if (skh_count_submit(ctx.c, bt.b, bt.nrec, pass_table[ps].data(), nc, bt.counts.data()) != SKH_OK)
+                    if (ctx.multi) {
+                        skh_multi* m = ctx.multi; skh_batch* b = bt.b; const uint64_t n = bt.nrec;
+                        const uint8_t* table = pass_table[ps].data();          // lives as long as the command
+                        uint64_t* out_counts = bt.counts.data();
+                        work[k].start([m, b, n, table, nc, out_counts] { return skh_count_multi(m, b, n, table, nc, out_counts); });
+                    } else if (skh_count_submit(ctx.c, bt.b, bt.nrec, pass_table[ps].data(), nc, bt.counts.data()) != SKH_OK)
                         return fatal(skh_last_error());
                 }
             }
@@ -1335,10 +1503,15 @@ int cmd_fx2tab(const GlobalOpts& g, const Fx2tabOpts& o, const std::vector<std::
             Batch& bt = tb.bt[cur];
             const bool got = rd.next_batch(bt, g.batch_bytes, g.batch_records);
             if (!rd.error().empty()) return fatal("error when parsing " + file + ": " + rd.error());
-            if (got && npass) if (int rc = count_batch(bt, cnt[cur])) return rc;
+            // (several GPUs: all of them work on one batch at a time, so the batch before comes back first)
+            if (have_prev && ctx.multi) {
+                if (work[cur ^ 1].wait() != SKH_OK) return fatal(work[cur ^ 1].err);
+                ctx.report_shares("fx2tab");
+            }
+            if (got && npass) if (int rc = count_batch(bt, cnt[cur], cur)) return rc;
             if (have_prev) {
                 Batch& pv = tb.bt[cur ^ 1];
-                if (skh_batch_wait(pv.b) != SKH_OK) return fatal(skh_last_error());
+                if (!ctx.multi && skh_batch_wait(pv.b) != SKH_OK) return fatal(skh_last_error());
                 finish_counts(pv, cnt[cur ^ 1]);
                 emit(pv, cnt[cur ^ 1]);
             }
@@ -1346,7 +1519,71 @@ int cmd_fx2tab(const GlobalOpts& g, const Fx2tabOpts& o, const std::vector<std::
             have_prev = true;
             cur ^= 1;
         }
+        return 0;
+    };
+
+    if (device_rows) {
+        for (const std::string& file : files) {
+            // (several GPUs and a first record longer than a text block: pinned batches, cut over all GPUs)
+            if (ctx.multi && !g.id_re && first_record_exceeds_block(file, g.text_block_bytes)) {
+                if (int rc = batch_file(file)) return rc;
+                continue;
+            }
+            BlockPipe tb(ctx.all, file, g.text_block_bytes);
+            if (!tb.ok()) return fatal(tb.error());
+            skh_parse_result res;
+            // every block is counted, formatted and downloaded by the worker of its GPU; the rows are
+            // written here in file order
+            auto step = [&](BlockJob& j) {
+                skh_text* t = j.t;
+                skh_ctx* c = skh_text_ctx(t);
+                auto failed = [&](const std::string& m) { j.rc = -1; j.err = m; };
+                if (j.res.nrec == 0) return;
+                {
+                    PhaseTimer pt(2);
+                    for (size_t ps = 0; ps < npass; ps++)
+                        if (skh_text_count(c, t, pass_table[ps].data(), pass_nclass[ps], (uint32_t)ps) != SKH_OK)
+                            return failed(skh_last_error());
+                }
+                if (o.alphabet_col) {                          // fx2tab.go:145-147
+                    PhaseTimer pt(2);
+                    if (skh_text_letters(c, t) != SKH_OK) return failed(skh_last_error());
+                }
+                skh_tab_format f = tf;
+                f.alphabet = o.alphabet_col ? 1 : 0;
+                f.only_id = o.only_id;
+                if (o.only_id && g.id_re) {
+                    std::vector<uint64_t> id_pos;
+                    std::vector<uint32_t> id_len;
+                    std::string err;
+                    if (custom_ids_as_names(g, t, j.res.nrec, id_pos, id_len, err)) return failed(err);
+                    f.only_id = 0;
+                }
+                f.print_seq = !o.only_name;
+                f.print_qual = !o.only_name && tb.is_fastq();
+                PhaseTimer pt(3);
+                if (skh_text_format_tab_submit(c, t, &f) != SKH_OK) return failed(skh_last_error());
+                if (skh_text_output_wait(c, t, &j.text, &j.nbytes) != SKH_OK) return failed(skh_last_error());
+            };
+            auto emit = [&](BlockJob& j) -> int {
+                if (j.nbytes) { PhaseTimer pt(4); out.write(j.text, j.nbytes); }
+                return 0;
+            };
+            {
+                BlockWorkers workers(ctx.all.size(), step);
+                OrderedBlocks line(tb, workers, 2 * ctx.all.size(), emit);
+                int rc = 0;
+                while (rc == 0 && tb.next(res)) rc = line.submit(res, false, step);
+                if (rc == 0) rc = line.finish();
+                if (rc) return rc;
+            }
+            if (!tb.error().empty()) return fatal(tb.error());
+        }
+        return 0;
     }
+
+    for (const std::string& file : files)
+        if (int rc = batch_file(file)) return rc;
     return 0;
 }
 
@@ -1414,36 +1651,55 @@ int cmd_stats(const GlobalOpts& g, const StatsOpts& o, const std::vector<std::st
     Batch bt;
     struct Free { Batch& b; ~Free() { if (b.b) skh_batch_free(b.b); } } guard{bt};
     for (const std::string& file : files) {
-        if (!g.host_parse) {
+        // (several GPUs and a first record longer than a text block: pinned batches, cut over all GPUs)
+        const bool batches = g.host_parse || (ctx.multi && first_record_exceeds_block(file, g.text_block_bytes));
+        if (!batches) {
             // file text parsed on the GPU: per block the totals kernel, and for -a the lengths
             BlockPipe tb(ctx.all, file, g.text_block_bytes);
             if (!tb.ok()) return fatal(tb.error());
-            // one partial per GPU the blocks are dealt to; merged at the end of the file
+            // one partial per GPU the blocks are dealt to (each GPU's worker adds to its own); merged at the
+            // end of the file
             std::vector<skh_stats_partial> part(ctx.all.size());
             for (auto& p : part) skh_stats_init(&p);
             std::vector<int64_t> lens;
-            std::vector<uint64_t> offs;
             bool fastq_first = false, first = true;
             int ab = -1;
             skh_parse_result res;
-            while (tb.next(res)) {
-                skh_text* t = tb.block();
-                if (res.nrec == 0) { tb.advance(res); continue; }
-                if (first || o.all) {
-                    const uint64_t cnt = o.all ? res.nrec + 1 : 2;
-                    offs.resize(cnt);
-                    if (skh_text_offsets(skh_text_ctx(t), t, 0, cnt, offs.data()) != SKH_OK) return fatal(skh_last_error());
+            auto step = [&](BlockJob& j) {
+                skh_text* t = j.t;
+                skh_ctx* c = skh_text_ctx(t);
+                auto failed = [&](const std::string& m) { j.rc = -1; j.err = m; };
+                if (j.res.nrec == 0) return;
+                if (o.all) {
+                    j.offs.resize(j.res.nrec + 1);
+                    if (skh_text_offsets(c, t, 0, j.res.nrec + 1, j.offs.data()) != SKH_OK) return failed(skh_last_error());
                 }
-                if (first) {
-                    fastq_first = tb.is_fastq() && offs[1] > offs[0];                 // stat.go:107-113
-                    std::string err;
-                    ab = first_record_alphabet(skh_text_ctx(t), t, g, g.alphabet, err);     // stat.go:87: config.Alphabet goes to the reader
-                    if (ab < 0) return fatal(err);
-                    first = false;
-                }
-                if (skh_text_stats(skh_text_ctx(t), t, is_gap, &part[(size_t)tb.device_index()]) != SKH_OK) return fatal(skh_last_error());
-                if (o.all) for (uint64_t r = 0; r < res.nrec; r++) lens.push_back((int64_t)(offs[r + 1] - offs[r]));
-                tb.advance(res);
+                if (skh_text_stats(c, t, is_gap, &part[(size_t)j.dev]) != SKH_OK) return failed(skh_last_error());
+            };
+            // the first block with records also tells the file's format and alphabet (stat.go:87,107-113)
+            auto step_first = [&](BlockJob& j) {
+                if (j.res.nrec == 0) return;
+                skh_text* t = j.t;
+                uint64_t two[2];
+                if (skh_text_offsets(skh_text_ctx(t), t, 0, 2, two) != SKH_OK) { j.rc = -1; j.err = skh_last_error(); return; }
+                fastq_first = tb.is_fastq() && two[1] > two[0];
+                std::string err;
+                ab = first_record_alphabet(skh_text_ctx(t), t, g, g.alphabet, err);     // stat.go:87: config.Alphabet goes to the reader
+                if (ab < 0) { j.rc = -1; j.err = err; return; }
+                first = false;
+                step(j);
+            };
+            auto emit = [&](BlockJob& j) -> int {
+                if (o.all) for (uint64_t r = 0; r < j.res.nrec; r++) lens.push_back((int64_t)(j.offs[r + 1] - j.offs[r]));
+                return 0;
+            };
+            {
+                BlockWorkers workers(ctx.all.size(), step);
+                OrderedBlocks line(tb, workers, 2 * ctx.all.size(), emit);
+                int rc = 0;
+                while (rc == 0 && tb.next(res)) rc = line.submit(res, first, step_first);
+                if (rc == 0) rc = line.finish();
+                if (rc) return rc;
             }
             if (!tb.error().empty()) return fatal(tb.error());
             if (part.size() > 1) {
@@ -1464,7 +1720,11 @@ int cmd_stats(const GlobalOpts& g, const StatsOpts& o, const std::vector<std::st
         while (rd.next_batch(bt, g.batch_bytes, g.batch_records)) {
             if (first) { fastq_first = rd.is_fastq() && bt.offs()[1] > 0; first = false; }   // stat.go:107-113
             // num, len_sum, gap_sum, len_min, len_max of the batch on the GPU (stat.go:106-125)
-            if (skh_stats_reduce(ctx.c, bt.b, bt.nrec, is_gap, &tot) != SKH_OK) return fatal(skh_last_error());
+            // (several GPUs: the batch is cut over all of them and their totals are all-reduced, skh_stats_multi)
+            const int rc = ctx.multi ? skh_stats_multi(ctx.multi, bt.b, bt.nrec, is_gap, &tot)
+                                     : skh_stats_reduce(ctx.c, bt.b, bt.nrec, is_gap, &tot);
+            if (rc != SKH_OK) return fatal(skh_last_error());
+            ctx.report_shares("stats");
             if (o.all) {
                 const uint64_t* off = bt.offs();
                 for (uint64_t r = 0; r < bt.nrec; r++) lens.push_back((int64_t)(off[r + 1] - off[r]));

@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 extern "C" {
@@ -730,6 +731,180 @@ int skh_stats_allreduce(skh_comm* c, skh_stats_partial* partials)
     skh_stats_init(&tot);
     for (size_t i = 0; i < c->ctx.size(); i++) skh_stats_merge(&tot, &partials[i]);
     for (size_t i = 0; i < c->ctx.size(); i++) partials[i] = tot;
+    return SKH_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------- one batch over several "GPUs"
+//
+// The header's rules restated: the plane is cut by skh_split_plane, every context's share is worked on
+// by a thread of its own (so the driver's use of these calls runs under ThreadSanitizer with real
+// concurrency), pieces of cut records land mirrored, rows of cut records are summed.
+
+struct skh_multi { std::vector<skh_ctx*> ctx; std::vector<skh_share_info> info; };
+
+namespace {
+
+template <typename F>
+void for_each_piece(const uint64_t* offs, uint64_t nrec, uint64_t b0, uint64_t b1, F&& f)     // f(record, a, b): slice [a, b) of the record
+{
+    if (b1 <= b0) return;
+    uint64_t lo = 0, hi = nrec;                  // last record that starts at or before b0
+    while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (offs[mid + 1] > b0) hi = mid; else lo = mid + 1; }
+    for (uint64_t r = lo; r < nrec && offs[r] < b1; r++) {
+        const uint64_t s = offs[r], e = offs[r + 1];
+        const uint64_t a = std::max(s, b0), b = std::min(e, b1);
+        if (b > a) f(r, a - s, b - s);
+    }
+}
+
+std::vector<uint64_t> cut_plane(skh_multi* m, const skh_batch* b, uint64_t nrec)
+{
+    std::vector<uint64_t> cuts(m->ctx.size() + 1);
+    skh_split_plane(b->offs.data(), nrec, (int)m->ctx.size(), cuts.data());
+    m->info.assign(m->ctx.size(), skh_share_info());
+    for (size_t k = 0; k < m->ctx.size(); k++) {
+        skh_share_info& si = m->info[k];
+        si.first_byte = cuts[k]; si.last_byte = cuts[k + 1]; si.chunks = 1;
+        bool first = true;
+        for_each_piece(b->offs.data(), nrec, cuts[k], cuts[k + 1], [&](uint64_t r, uint64_t a, uint64_t e) {
+            if (first) { si.first_record = r; si.head_cut = a; first = false; }
+            si.nrecords = r + 1 - si.first_record;
+            si.tail_cut = b->offs[r + 1] - b->offs[r] - e;
+        });
+    }
+    return cuts;
+}
+
+template <typename F>
+void on_every_share(skh_multi* m, F&& f)         // f(k) on a thread per context
+{
+    std::vector<std::thread> thr;
+    for (size_t k = 1; k < m->ctx.size(); k++) thr.emplace_back([&f, k] { f(k); });
+    f(0);
+    for (auto& t : thr) t.join();
+}
+
+}  // namespace
+
+extern "C" {
+
+int skh_split_plane(const uint64_t* offsets, uint64_t nrec, int nparts, uint64_t* cuts)
+{
+    if (!offsets || !cuts || nparts < 1) return fail(SKH_EINVAL, "skh_split_plane: bad argument");
+    const uint64_t total = offsets[nrec], tol = total / (uint64_t)nparts / 16;
+    cuts[0] = 0;
+    for (int k = 1; k < nparts; k++) {
+        const uint64_t target = (uint64_t)((unsigned __int128)total * (unsigned)k / (unsigned)nparts);
+        const uint64_t r = (uint64_t)(std::lower_bound(offsets, offsets + nrec, target) - offsets);
+        uint64_t cut = offsets[r];
+        if (cut != target) {
+            const uint64_t s = offsets[r - 1], e = offsets[r];
+            if (e - target <= tol && e - target <= target - s) cut = e;
+            else if (target - s <= tol) cut = s;
+            else cut = s + ((target - s) & ~15ull);
+        }
+        cuts[k] = std::max(cut, cuts[k - 1]);
+    }
+    cuts[nparts] = total;
+    return SKH_OK;
+}
+
+int skh_multi_init(skh_ctx* const* ctxs, int n, skh_multi** out)
+{
+    if (!ctxs || !out || n < 1) return fail(SKH_EINVAL, "skh_multi_init: bad argument");
+    *out = new skh_multi;
+    (*out)->ctx.assign(ctxs, ctxs + n);
+    (*out)->info.assign((size_t)n, skh_share_info());
+    return SKH_OK;
+}
+void skh_multi_destroy(skh_multi* m) { delete m; }
+int skh_multi_size(const skh_multi* m) { return m ? (int)m->ctx.size() : 0; }
+int skh_multi_shares(const skh_multi* m, skh_share_info* info)
+{
+    if (!m || !info) return fail(SKH_EINVAL, "NULL argument");
+    std::copy(m->info.begin(), m->info.end(), info);
+    return SKH_OK;
+}
+
+int skh_revcomp_multi(skh_multi* m, skh_batch* b, uint64_t nrec, const uint8_t* lut, int do_reverse, int reverse_qual)
+{
+    if (!m) return fail(SKH_EINVAL, "multi is NULL");
+    if (int rc = batch_check(b, nrec)) return rc;
+    if (b->offs[nrec] == 0 || (!lut && !do_reverse)) return SKH_OK;
+    const std::vector<uint64_t> cuts = cut_plane(m, b, nrec);
+    const bool qual = b->with_qual && reverse_qual && do_reverse;
+    std::vector<uint8_t> out_seq(b->seq.size()), out_qual(qual ? b->qual.size() : 0);
+    on_every_share(m, [&](size_t k) {
+        for_each_piece(b->offs.data(), nrec, cuts[k], cuts[k + 1], [&](uint64_t r, uint64_t a, uint64_t e) {
+            const uint64_t s = b->offs[r], len = b->offs[r + 1] - s;
+            for (uint64_t i = a; i < e; i++) {
+                const uint64_t dst = do_reverse ? s + len - 1 - i : s + i;
+                const uint8_t c = b->seq[s + i];
+                out_seq[dst] = lut ? lut[c] : c;
+                if (qual) out_qual[dst] = b->qual[s + i];
+            }
+        });
+    });
+    memcpy(b->seq.data(), out_seq.data(), b->offs[nrec]);
+    if (qual) memcpy(b->qual.data(), out_qual.data(), b->offs[nrec]);
+    return SKH_OK;
+}
+
+int skh_count_multi(skh_multi* m, skh_batch* b, uint64_t nrec, const uint8_t class_of[256], uint32_t nclass, uint64_t* counts)
+{
+    if (!m || !class_of) return fail(SKH_EINVAL, "NULL argument");
+    if (int rc = batch_check(b, nrec)) return rc;
+    if (nclass < 1 || nclass > SKH_MAX_CLASSES) return fail(SKH_EINVAL, "nclass must be 1..SKH_MAX_CLASSES");
+    if (nrec == 0) return SKH_OK;
+    if (!counts) return fail(SKH_EINVAL, "counts pointer is NULL");
+    const std::vector<uint64_t> cuts = cut_plane(m, b, nrec);
+    struct Row { uint64_t record; uint64_t v[SKH_MAX_CLASSES]; };
+    std::vector<std::vector<Row>> rows(m->ctx.size());
+    on_every_share(m, [&](size_t k) {
+        for_each_piece(b->offs.data(), nrec, cuts[k], cuts[k + 1], [&](uint64_t r, uint64_t a, uint64_t e) {
+            Row row;
+            row.record = r;
+            memset(row.v, 0, sizeof row.v);
+            for (uint64_t i = a; i < e; i++) {
+                const uint8_t c = class_of[b->seq[b->offs[r] + i]];
+                if (c != SKH_NO_CLASS) row.v[c]++;
+            }
+            rows[k].push_back(row);
+        });
+    });
+    memset(counts, 0, nrec * nclass * sizeof(uint64_t));
+    for (const auto& share : rows)
+        for (const Row& row : share)
+            for (uint32_t c = 0; c < nclass; c++) counts[row.record * nclass + c] += row.v[c];
+    return SKH_OK;
+}
+
+int skh_stats_multi(skh_multi* m, skh_batch* b, uint64_t nrec, const uint8_t is_gap[256], skh_stats_partial* inout)
+{
+    if (!m || !is_gap || !inout) return fail(SKH_EINVAL, "NULL argument");
+    if (int rc = batch_check(b, nrec)) return rc;
+    if (nrec == 0) return SKH_OK;
+    const std::vector<uint64_t> cuts = cut_plane(m, b, nrec);
+    std::vector<skh_stats_partial> part(m->ctx.size());
+    on_every_share(m, [&](size_t k) {
+        skh_stats_partial& p = part[k];
+        skh_stats_init(&p);
+        // a record counts where it starts; gap letters and bytes are those of the share
+        const uint64_t b0 = cuts[k], b1 = cuts[k + 1];
+        const bool last = k + 1 == m->ctx.size();
+        for (uint64_t r = (uint64_t)(std::lower_bound(b->offs.data(), b->offs.data() + nrec, b0) - b->offs.data());
+             r < nrec && (b->offs[r] < b1 || last); r++) {
+            const int64_t len = (int64_t)(b->offs[r + 1] - b->offs[r]);
+            p.num++;
+            p.len_min = std::min(p.len_min, len);
+            p.len_max = std::max(p.len_max, len);
+        }
+        p.len_sum = (int64_t)(b1 - b0);
+        for (uint64_t i = b0; i < b1; i++) p.gap_sum += is_gap[b->seq[i]] ? 1 : 0;
+    });
+    for (const auto& p : part) skh_stats_merge(inout, &p);
     return SKH_OK;
 }
 

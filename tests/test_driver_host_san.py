@@ -138,6 +138,47 @@ def test_blocks_dealt_to_several_devices(san, oracle_cli, which, tmp_path, monke
     assert rc == 255 and b"[ERRO] device ordinal out of range" in err
 
 
+def long_record_files(tmp_path):
+    """one.fa: a single record of 1.2 Mb; mixed.fa: a long first record, short and empty ones, another long one."""
+    import numpy as np
+    rng = np.random.default_rng(4)
+    paths = []
+    for name, lens in (("one.fa", [1_200_003]), ("mixed.fa", [700_000, 12, 0, 250_000, 90_000, 5])):
+        path = tmp_path / name
+        with open(path, "wb") as fh:
+            for i, n in enumerate(lens):
+                s = rng.choice(np.frombuffer(b"ACGTacgtNn-", np.uint8), size=n).tobytes()
+                fh.write(b">c%d some text\n" % i)
+                for a in range(0, n, 60):
+                    fh.write(s[a:a + 60] + b"\n")
+        paths.append(str(path))
+    return paths
+
+
+@pytest.mark.parametrize("which", ["asan", "tsan"])
+def test_one_batch_over_several_devices(san, oracle_cli, which, tmp_path, monkeypatch):
+    # several GPUs: pinned batches (--host-parse, and any file whose first record is longer than a text
+    # block) are cut over ALL devices, inside records where they are long; SKH_SHARES=1 shows the cuts
+    monkeypatch.setenv("SKH_STUB_DEVICES", "8")
+    monkeypatch.setenv("SKH_SHARES", "1")
+    one, mixed = long_record_files(tmp_path)
+    for argv in (["seq", "-r", "-p"], ["seq", "-p", "-w", "0"], ["fx2tab", "-n", "-l", "-g", "-B", "AGCT"], ["stats", "-a", "-T"]):
+        for f in (one, mixed, "reads_1.fq.gz"):
+            want = run_cli(oracle_cli, argv + [f])
+            for dev in (["--gpus", "2"], ["--devices", "0,1,2"], ["--gpus", "8"]):
+                for mode in ([], ["--host-parse", "--batch-records", "700"]):
+                    got = clean(run_cli(san[which], argv + dev + mode + ["--batch-bytes", "65536"] + [f]))
+                    assert got[0] == want[0] == 0 and got[1] == want[1], (argv, f, dev, mode, got[2][-500:])
+                    shares = [l for l in got[2].decode().splitlines() if l.startswith("[shares]")]
+                    routed = bool(mode) or f in (one, mixed)
+                    assert bool(shares) == routed, (argv, f, mode)
+                    if f == one and shares:
+                        # every device worked on a piece of the one record
+                        n = 2 if dev[1] == "2" else 3 if dev[1] == "0,1,2" else 8
+                        assert len(shares) >= n and all("records 0..1" in l for l in shares[:n])
+                        assert sum("head_cut 0 " not in l for l in shares[:n]) == n - 1
+
+
 def test_fasta_after_fastq_keeps_the_fastq_layout(san, oracle_cli):
     # seq.go:140-149: the layout is decided once; records of a later FASTA file get "+" and an empty quality
     want = run_cli(oracle_cli, ["seq", "reads_1.fq.gz", "contigs.fa"])

@@ -51,6 +51,43 @@ def test_driver_multiline_fastq_over_several_contexts(oracle_cli, tmp_path):
         assert got[0] == 0 and got[1] == want[1]
 
 
+def test_one_record_cut_over_three_contexts(oracle_cli, tmp_path):
+    """`--devices 0,0,0` on a file that is one 5 Mb record, and on a file with long and short records mixed:
+    the file goes through a pinned batch that is cut over all contexts (inside the long records), and the
+    output is the oracle's byte for byte.  SKH_SHARES=1 makes the driver print what every context was given."""
+    rng = np.random.default_rng(4)
+    files = {}
+    for name, lens in (("one.fa", [5_000_003]), ("mixed_long.fa", [1_200_000, 12, 0, 700_001, 90_000, 5] + [150] * 3000)):
+        path = str(tmp_path / name)
+        with open(path, "wb") as fh:
+            for i, n in enumerate(lens):
+                s = rng.choice(np.frombuffer(b"ACGTacgtNn-", np.uint8), size=n).tobytes()
+                fh.write(b">c%d some text\n" % i)
+                for a in range(0, n, 60):
+                    fh.write(s[a:a + 60] + b"\n")
+        files[name] = path
+    env = dict(os.environ, SKH_SHARES="1")
+    import subprocess
+    for argv in (["seq", "-r", "-p"], ["seq", "-r", "-p", "-w", "0"], ["fx2tab", "-n", "-l", "-g", "-B", "AGCT"], ["stats", "-a", "-T"]):
+        for name, path in files.items():
+            want = run_cli(oracle_cli, argv + [path])
+            for extra in (["--batch-bytes", "1000000"], ["--host-parse"]):
+                p = subprocess.run([CLI] + argv + ["--devices", "0,0,0"] + extra + [path], stdout=subprocess.PIPE,
+                                   stderr=subprocess.PIPE, env=env, timeout=300)
+                assert p.returncode == 0 and p.stdout == want[1], (argv, name, extra, p.stderr[-400:])
+                shares = [l for l in p.stderr.decode().splitlines() if l.startswith("[shares]")]
+                assert len(shares) >= 3, p.stderr[-400:]
+                if name == "one.fa":
+                    # all three contexts worked on the one record: two of the shares start inside it
+                    first = shares[:3]
+                    assert all("records 0..1" in l for l in first) and sum("head_cut 0 " not in l for l in first) == 2
+    # one context: the same files stay on the text path (nothing is cut)
+    p = subprocess.run([CLI, "seq", "-r", "-p", "--batch-bytes", "1000000", files["one.fa"]], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, env=env, timeout=300)
+    assert p.returncode == 0 and b"[shares]" not in p.stderr
+    assert p.stdout == run_cli(oracle_cli, ["seq", "-r", "-p", files["one.fa"]])[1]
+
+
 def test_fasta_after_fastq_and_stats_type(oracle_cli):
     want = run_cli(oracle_cli, ["seq", "reads_1.fq.gz", "contigs.fa"])
     assert want[1].endswith(b"@length=9\nAAAAAAAAA\n+\n\n")
