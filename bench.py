@@ -77,6 +77,7 @@ def parse():
     ap.add_argument("--nrec", type=int, default=10_000_000, help="records per GPU (default: configs[1])")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline budget per leg (0 = skip)")
+    ap.add_argument("--sustain", type=float, default=2.0, help="seconds of the same step run on after the timed steps (0 = skip)")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the file-to-file run of the driver")
     ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configurations")
@@ -300,7 +301,7 @@ def offsets_of(lengths, dev):
     return torch.from_numpy(offs).to(dev), int(offs[-1])
 
 
-def other_configs(b, rank, world):
+def other_configs(b, rank, world, host_xfer=False):
     """BASELINE configs[2], [4] and [3] (kernels only).  One rank: the whole configuration on this GPU.
     Several ranks: the same total work cut by byte volume (seqkit_amd.shard), every rank timing its share;
     rank 0 reports the slowest share (strong scaling)."""
@@ -333,25 +334,78 @@ def other_configs(b, rank, world):
     del seq, offs, counts
     torch.cuda.empty_cache()
 
-    # configs[4]: 24 records with the GRCh38 chromosome lengths; ranks take byte-volume shares cut inside the records
-    pieces = shard.plan_pieces(GRCH38, world)[rank]
+    # configs[4]: ONE batch of 24 records with the GRCh38 chromosome lengths, the same on every rank (same seed);
+    # the library's rule (skh_split_plane) cuts it into `world` shares of equal byte volume, inside the records;
+    # every rank reverse-complements and counts its share, the pieces are gathered on rank 0, put at their
+    # mirrored places [L-b, L-a) and compared with the whole batch done on one GPU
+    offs_all, all_total = offsets_of(GRCH38, dev)
+    offs_np = offs_all.cpu().numpy().astype(np.uint64)
+    cuts = np.zeros(world + 1, np.uint64)
+    b.lib.check(b.lib.skh_split_plane(offs_np.ctypes.data_as(C.POINTER(C.c_uint64)), 24, world,
+                                      cuts.ctypes.data_as(C.POINTER(C.c_uint64))))
+    assert [int(c) for c in cuts] == shard.split_plane(offs_np, world)
+    whole, _ = synth_plane(all_total, 0xC5, dev, soft[0], soft[1], p_n=0)
+    b0, b1 = int(cuts[rank]), int(cuts[rank + 1])
+    pieces = shard.pieces_of_share(offs_np, b0, b1)
     lens = [p[2] - p[1] for p in pieces]
     offs, total = offsets_of(lens, dev)
     nrec = len(lens)
-    seq, _ = synth_plane(total, 0xC5 + rank, dev, soft[0], soft[1], p_n=0)
-    outp, back = torch.empty_like(seq), torch.empty_like(seq)
+    assert total == b1 - b0
+    seq = torch.zeros((total + 15) & ~15, dtype=torch.uint8, device=dev)
+    seq[:total] = whole[b0:b1]
+    outp = torch.empty_like(seq)
     counts = torch.empty(nrec * 4, dtype=torch.int64, device=dev)
-    all_total = sum(GRCH38)
     ms_rev = slowest(b.time_ms(lambda: b.revcomp(seq, outp, offs, nrec, total)))
     ms_cnt = slowest(b.time_ms(lambda: b.count(seq, offs, nrec, total, counts)))
-    b.revcomp(outp, back, offs, nrec, total)
     torch.cuda.synchronize()
-    ok = bool(torch.equal(back[:total], seq[:total]))
+    # rank 0: the whole batch on one GPU, and the gathered pieces beside it
+    ok, md5 = True, None
+    if rank == 0:
+        whole_out = torch.empty_like(whole)
+        whole_cnt = torch.empty(24 * 4, dtype=torch.int64, device=dev)
+        b.revcomp(whole, whole_out, offs_all, 24, all_total)
+        b.count(whole, offs_all, 24, all_total, whole_cnt)
+        torch.cuda.synchronize()
+        joined = torch.zeros_like(whole)
+        joined_cnt = torch.zeros(24, 4, dtype=torch.int64, device=dev)
+    for src in range(world):
+        if rank != 0 and rank != src:
+            continue
+        sb0, sb1 = int(cuts[src]), int(cuts[src + 1])
+        spieces = pieces if src == rank else shard.pieces_of_share(offs_np, sb0, sb1)
+        if src == 0:
+            part_out, part_cnt = outp[:total], counts.view(nrec, 4)
+        elif rank == src:
+            for t in (outp[:total].contiguous(), counts.view(nrec, 4).contiguous()):
+                dist.send(t.cpu() if host_xfer else t, dst=0)
+            continue
+        else:
+            xdev = "cpu" if host_xfer else dev        # (a gloo rehearsal moves host tensors)
+            part_out = torch.empty(sb1 - sb0, dtype=torch.uint8, device=xdev)
+            part_cnt = torch.empty((len(spieces), 4), dtype=torch.int64, device=xdev)
+            dist.recv(part_out, src=src)
+            dist.recv(part_cnt, src=src)
+            part_out, part_cnt = part_out.to(dev), part_cnt.to(dev)
+        pos = 0
+        for i, (r, a, e) in enumerate(spieces):          # piece [a, e) of record r, reversed, belongs at [L-e, L-a)
+            s0, L = int(offs_np[r]), int(offs_np[r + 1] - offs_np[r])
+            joined[s0 + L - e:s0 + L - a] = part_out[pos:pos + (e - a)]
+            joined_cnt[r] += part_cnt[i]
+            pos += e - a
+    if rank == 0:
+        ok = bool(torch.equal(joined[:all_total], whole_out[:all_total])) and bool(torch.equal(joined_cnt.view(-1), whole_cnt))
+        if os.environ.get("SKH_BENCH_MD5"):
+            md5 = hashlib.md5(joined[:all_total].cpu().numpy().tobytes()).hexdigest()
+        del whole_out, joined
     out["configs[4] revcomp 24 chromosomes"] = dict(figure(ms_rev, 2 * all_total + 8 * 24, all_total), verified=ok,
                                                     pieces_per_rank=nrec, bytes_per_rank=total,
+                                                    check="one shared batch cut by skh_split_plane; the ranks' pieces gathered on rank 0 "
+                                                          "equal the whole batch reverse-complemented on one GPU",
                                                     scaling="strong (cuts inside records)" if world > 1 else "single GPU")
+    if md5:
+        out["configs[4] revcomp 24 chromosomes"]["output_md5"] = md5
     out["configs[4] count4 24 chromosomes"] = dict(figure(ms_cnt, all_total + 40 * 24, all_total), bytes_per_rank=total)
-    del seq, outp, back, counts, offs
+    del seq, outp, counts, offs, whole
     torch.cuda.empty_cache()
 
     # configs[3]: nanopore-like lengths (log-normal, 1 kbp - 1 Mbp), stats / revcomp / counts; contiguous
@@ -458,6 +512,26 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # the same step for a longer stretch (the timed steps above may take milliseconds): what the GPU sustains
+    sustained = None
+    if args.sustain > 0:
+        done, t_s = 0, time.perf_counter()
+        while True:
+            for _ in range(50):
+                revcomp_bases(); reverse_quals(); count()
+            done += 50
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t_s
+            if el >= args.sustain:
+                break
+        if world > 1:
+            t = torch.tensor([done / el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            rate = float(t.item())
+        else:
+            rate = done / el
+        sustained = {"seconds": round(el, 3), "steps": done, "gbases_per_s": round(world * total * rate / 1e9, 3),
+                     "ms_per_step": round(1e3 / rate, 4)}
     rev_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / args.steps
     qual_ms = sum(e[1].elapsed_time(e[2]) for e in ev) / args.steps
     cnt_ms = sum(e[2].elapsed_time(e[3]) for e in ev) / args.steps
@@ -522,7 +596,7 @@ def main():
         if world > 1:                                    # every GPU needs the room; the e2e leg (N = 1) needs the batch
             del seq_out, qual_out, counts
             torch.cuda.empty_cache()
-        configs = other_configs(b, rank, world)
+        configs = other_configs(b, rank, world, host_xfer=args.rehearse)
         seq, qual = keep
 
     if rank == 0:
@@ -564,6 +638,8 @@ def main():
                       "comm_init_s": None if comm_init_s is None else round(comm_init_s, 3)},
             "verified": ok,
         }
+        if sustained is not None:
+            out["sustained"] = sustained
         if configs is not None:
             out["configs"] = configs
         if args.cpu_seconds > 0 and world == 1:
