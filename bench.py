@@ -568,6 +568,12 @@ def main():
         ok_stats = stats[:2] == [nrec * world, total * world] and stats[3:] == [L, L]
         assert ok_stats, stats
         lib.skh_comm_destroy(comm)
+    rccl = None
+    if not args.no_collective:
+        v = [C.c_int(0), C.c_int(0), C.c_int(0)]
+        lib.check(lib.skh_comm_rccl_version(C.byref(v[0]), C.byref(v[1]), C.byref(v[2])))
+        rccl = {"ncclGetVersion": v[0].value, "header_NCCL_VERSION_CODE": v[1].value,
+                "library": "the copy the process held (torch's)" if v[2].value else "opened by libseqkit_hip.so"}
 
     # the same reverse-complement with one plane (skh_revcomp_inplace_dev), outside the timed steps
     work = seq.clone()
@@ -635,7 +641,7 @@ def main():
             "stats": {"totals": stats, "collective": "skh_stats_allreduce_dev: RCCL all-reduce of 5 x int64 (sum x3, min, max) "
                                                      "inside libseqkit_hip.so, %d rank(s)" % world,
                       "allreduce_us": [round(x, 1) for x in allreduce_us],
-                      "comm_init_s": None if comm_init_s is None else round(comm_init_s, 3)},
+                      "comm_init_s": None if comm_init_s is None else round(comm_init_s, 3), "rccl": rccl},
             "verified": ok,
         }
         if sustained is not None:

@@ -463,7 +463,14 @@ skh_ctx *skh_text_ctx(const skh_text *t);
  * A communicator is made either over several contexts of ONE process (skh_comm_init_all: the
  * driver's --gpus N; contexts that share a device are merged on the host first) or as one rank of a
  * multi-process job, one GPU per process (rank 0 calls skh_comm_unique_id, hands the bytes to the
- * other ranks by any means it has, every rank calls skh_comm_init_rank).  RCCL is loaded on first use. */
+ * other ranks by any means it has, every rank calls skh_comm_init_rank).  RCCL is loaded on first use
+ * (the copy the process already holds, if any).  RCCL itself may print a line about its version on
+ * standard output while a communicator is made (skh_comm_unique_id, skh_comm_init_all,
+ * skh_comm_init_rank, skh_multi_comm_init and the first skh_stats_multi): a caller whose standard
+ * output carries data must not have another thread writing to it during those calls, and may point
+ * file descriptor 1 elsewhere around them.  skh_comm_rccl_version reports ncclGetVersion() of the
+ * RCCL in use, the NCCL_VERSION_CODE of the header the library was compiled against, and whether
+ * the RCCL in use was already loaded by the process (1) or opened by this library (0). */
 typedef struct skh_comm skh_comm;
 #define SKH_COMM_ID_BYTES 128
 int skh_split_by_bytes(const uint64_t *offsets, uint64_t nrec, int nparts, uint64_t *cuts);
@@ -475,6 +482,7 @@ int skh_comm_init_rank(skh_ctx *ctx, const uint8_t id[SKH_COMM_ID_BYTES], int nr
 void skh_comm_destroy(skh_comm *c);
 /* GPUs of this process in the communicator (distinct devices of skh_comm_init_all; 1 for init_rank). */
 int skh_comm_local_ranks(const skh_comm *c);
+int skh_comm_rccl_version(int *runtime_version, int *header_version, int *shared_with_process);
 /* Host form: partials[i] belongs to context i of skh_comm_init_all (one entry for init_rank); on
  * return every entry holds the totals over all GPUs and processes.  Synchronous. */
 int skh_stats_allreduce(skh_comm *c, skh_stats_partial *partials);
@@ -555,6 +563,9 @@ int  skh_split_plane(const uint64_t *offsets, uint64_t nrec, int nparts, uint64_
 int  skh_multi_init(skh_ctx *const *ctxs, int n, skh_multi **out);
 void skh_multi_destroy(skh_multi *m);
 int  skh_multi_size(const skh_multi *m);
+/* Makes the communicator skh_stats_multi needs ahead of its first call (see "several GPUs" about
+ * RCCL and standard output); without it the first skh_stats_multi makes it. */
+int  skh_multi_comm_init(skh_multi *m);
 int  skh_revcomp_multi(skh_multi *m, skh_batch *b, uint64_t nrec, const uint8_t *lut, int do_reverse,
                        int reverse_qual);
 int  skh_count_multi(skh_multi *m, skh_batch *b, uint64_t nrec, const uint8_t class_of[256], uint32_t nclass,

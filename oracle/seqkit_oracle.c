@@ -347,10 +347,11 @@ ora_reader *ora_reader_open(const char *path, int forced_alphabet, size_t guess_
     return r;
 }
 
+/* \s of the default expression `^([^\s]+)\s?` is Go's (RE2's): [\t\n\f\r ] -- a vertical tab is not white space */
 static size_t id_length(const uint8_t *name, size_t n)
 {
     size_t i = 0;
-    while (i < n && !(name[i] == ' ' || (name[i] >= '\t' && name[i] <= '\r'))) i++;
+    while (i < n && !(name[i] == ' ' || (name[i] >= '\t' && name[i] <= '\r' && name[i] != '\v'))) i++;
     return i == 0 ? n : i;   /* regexp does not match -> whole head */
 }
 

@@ -139,6 +139,8 @@ SYMBOLS = {
     "skh_comm_init_rank": (C.c_int, [vp, u8p, C.c_int, C.c_int, C.POINTER(vp)]),
     "skh_comm_destroy": (None, [vp]),
     "skh_comm_local_ranks": (C.c_int, [vp]),
+    "skh_comm_rccl_version": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "skh_multi_comm_init": (C.c_int, [vp]),
     "skh_stats_allreduce": (C.c_int, [vp, C.POINTER(StatsPartial)]),
     "skh_stats_allreduce_dev": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp)]),
     "skh_split_plane": (C.c_int, [u64p, C.c_uint64, C.c_int, u64p]),

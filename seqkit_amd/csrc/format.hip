@@ -29,11 +29,12 @@ __device__ __forceinline__ uint64_t wrapped_len(uint64_t len, uint32_t width)
 }
 
 // ID = head line up to the first white space; the whole line if it starts with white space
-// (the default --id-regexp `^([^\s]+)\s?` does not match then).
+// (the default --id-regexp `^([^\s]+)\s?` does not match then).  \s is Go's (RE2's) [\t\n\f\r ]: a
+// vertical tab is part of the ID.
 __device__ __forceinline__ uint32_t id_length(const uint8_t* __restrict__ name, uint32_t n)
 {
     uint32_t i = 0;
-    while (i < n && !(name[i] == ' ' || (name[i] >= '\t' && name[i] <= '\r'))) i++;
+    while (i < n && !(name[i] == ' ' || (name[i] >= '\t' && name[i] <= '\r' && name[i] != '\v'))) i++;
     return i == 0 ? n : i;
 }
 

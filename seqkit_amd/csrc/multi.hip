@@ -8,9 +8,11 @@
 // (seqkit/cmd/stat.go:106-125: sum of num / len_sum / gap_sum, min of len_min, max of len_max)
 // over RCCL: three all-reduces of int64 in one group on a 40-byte buffer, latency-bound.
 //
-// RCCL is loaded when the first communicator is made (dlopen; a process that already holds an
-// RCCL, e.g. under torch.distributed, is given that one), so single-GPU users of the library
-// never load it.
+// RCCL is loaded when the first communicator is made (a process that already holds an RCCL, e.g.
+// under torch.distributed, is given that one: its symbols are found in the global scope; otherwise
+// the library is opened with dlopen), so single-GPU users of the library never load it.  RCCL may
+// announce itself on standard output while a communicator is made; a caller whose standard output
+// is its data points file descriptor 1 elsewhere around those calls (the driver does).
 #include "seqkit_hip.h"
 
 #include <dlfcn.h>
@@ -37,7 +39,9 @@ struct Rccl {
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclGetVersion) GetVersion = nullptr;
     bool ok = false;
+    bool global = false;       // the symbols came from a copy the process held already
 };
 
 Rccl g_rccl;
@@ -45,23 +49,27 @@ std::once_flag g_rccl_once;
 
 void load_rccl()
 {
-    // a copy the process already holds comes first: two RCCLs in one process do not share their state
-    void* h = dlsym(RTLD_DEFAULT, "ncclAllReduce") ? RTLD_DEFAULT : nullptr;
-    if (!h) {
+    // a copy the process already holds comes first (two RCCLs in one process do not share their state):
+    // its symbols are looked up in the global scope; only when there is none is the library opened here
+    const bool have_global = dlsym(RTLD_DEFAULT, "ncclAllReduce") != nullptr;
+    void* h = nullptr;
+    if (!have_global) {
         for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
             h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
             if (h) break;
         }
+        if (!h) return;
     }
-    if (!h) return;
+    void* from = have_global ? RTLD_DEFAULT : h;
     Rccl r;
-#define SKH_SYM(field, sym) r.field = reinterpret_cast<decltype(r.field)>(dlsym(h, #sym))
+#define SKH_SYM(field, sym) r.field = reinterpret_cast<decltype(r.field)>(dlsym(from, #sym))
     SKH_SYM(GetUniqueId, ncclGetUniqueId); SKH_SYM(CommInitRank, ncclCommInitRank); SKH_SYM(CommInitAll, ncclCommInitAll);
     SKH_SYM(CommDestroy, ncclCommDestroy); SKH_SYM(AllReduce, ncclAllReduce); SKH_SYM(GroupStart, ncclGroupStart);
-    SKH_SYM(GroupEnd, ncclGroupEnd); SKH_SYM(GetErrorString, ncclGetErrorString);
+    SKH_SYM(GroupEnd, ncclGroupEnd); SKH_SYM(GetErrorString, ncclGetErrorString); SKH_SYM(GetVersion, ncclGetVersion);
 #undef SKH_SYM
     r.ok = r.GetUniqueId && r.CommInitRank && r.CommInitAll && r.CommDestroy && r.AllReduce && r.GroupStart &&
            r.GroupEnd && r.GetErrorString;
+    r.global = have_global;
     g_rccl = r;
 }
 
@@ -72,15 +80,6 @@ int need_rccl()
     const char* why = dlerror();
     return skh::set_error(SKH_ENODEV, "RCCL (librccl.so) could not be loaded: %s", why ? why : "missing symbols");
 }
-
-// RCCL announces itself on standard output when a communicator is made ("RCCL version : ...").  The
-// standard output of a process that uses this library is its data (the driver writes records there),
-// so file descriptor 1 points at standard error while RCCL initialises.
-struct StdoutToStderr {
-    int saved;
-    StdoutToStderr() { fflush(stdout); saved = dup(1); if (saved >= 0) (void)dup2(2, 1); }
-    ~StdoutToStderr() { fflush(stdout); if (saved >= 0) { (void)dup2(saved, 1); close(saved); } }
-};
 
 int rccl_fail(ncclResult_t r, const char* what) { return skh::set_error(SKH_EHIP, "%s: %s", what, g_rccl.GetErrorString(r)); }
 int hip_fail(hipError_t e, const char* what) { return skh::set_error(SKH_EHIP, "%s: %s", what, hipGetErrorString(e)); }
@@ -145,10 +144,7 @@ int skh_comm_unique_id(uint8_t id[SKH_COMM_ID_BYTES])
     if (!id) return skh::set_error(SKH_EINVAL, "NULL argument");
     if (int rc = need_rccl()) return rc;
     ncclUniqueId u;
-    {
-        StdoutToStderr quiet;
-        RCCL_TRY(g_rccl.GetUniqueId(&u));
-    }
+    RCCL_TRY(g_rccl.GetUniqueId(&u));
     memcpy(id, u.internal, SKH_COMM_ID_BYTES);
     return SKH_OK;
 }
@@ -194,7 +190,6 @@ int skh_comm_init_all(skh_ctx* const* ctxs, int n, skh_comm** out)
     c->device = devices;
     int rc = comm_buffers(c);
     if (rc == SKH_OK) {
-        StdoutToStderr quiet;
         const ncclResult_t r = g_rccl.CommInitAll(c->comm.data(), c->nlocal, c->device.data());
         if (r != ncclSuccess) rc = rccl_fail(r, "ncclCommInitAll");
     }
@@ -216,7 +211,6 @@ int skh_comm_init_rank(skh_ctx* ctx, const uint8_t id[SKH_COMM_ID_BYTES], int nr
     if (rc == SKH_OK) {
         ncclUniqueId u;
         memcpy(u.internal, id, SKH_COMM_ID_BYTES);
-        StdoutToStderr quiet;
         const ncclResult_t r = g_rccl.CommInitRank(&c->comm[0], nranks, u, rank);     // the device is current (comm_buffers)
         if (r != ncclSuccess) rc = rccl_fail(r, "ncclCommInitRank");
     }
@@ -240,6 +234,17 @@ void skh_comm_destroy(skh_comm* c)
 }
 
 int skh_comm_local_ranks(const skh_comm* c) { return c ? c->nlocal : 0; }
+
+int skh_comm_rccl_version(int* runtime_version, int* header_version, int* shared_with_process)
+{
+    if (int rc = need_rccl()) return rc;
+    int v = 0;
+    if (g_rccl.GetVersion && g_rccl.GetVersion(&v) != ncclSuccess) v = 0;
+    if (runtime_version) *runtime_version = v;
+    if (header_version) *header_version = NCCL_VERSION_CODE;
+    if (shared_with_process) *shared_with_process = g_rccl.global ? 1 : 0;
+    return SKH_OK;
+}
 
 // sum of {num, len_sum, gap_sum}, min of len_min, max of len_max, in place, over all ranks
 static int allreduce_group(skh_comm* c, skh_stats_partial* const* d_partial, const hipStream_t* streams)

@@ -518,6 +518,15 @@ void skh_multi_destroy(skh_multi* m)
 
 int skh_multi_size(const skh_multi* m) { return m ? (int)m->w.size() : 0; }
 
+int skh_multi_comm_init(skh_multi* m)
+{
+    if (!m) return skh::set_error(SKH_EINVAL, "multi is NULL");
+    if (m->comm || m->w.size() < 2) return SKH_OK;
+    std::vector<skh_ctx*> ctxs;
+    for (const Worker& w : m->w) ctxs.push_back(w.ctx);
+    return skh_comm_init_all(ctxs.data(), (int)ctxs.size(), &m->comm);
+}
+
 int skh_multi_shares(const skh_multi* m, skh_share_info* info)
 {
     if (!m || !info) return skh::set_error(SKH_EINVAL, "NULL argument");
@@ -573,11 +582,7 @@ int skh_stats_multi(skh_multi* m, skh_batch* b, uint64_t nrec, const uint8_t is_
     if (m->w.size() > 1) {
         // the path's one collective: the totals of the shares all-reduced over RCCL (contexts that share
         // a GPU are merged on the host first)
-        if (!m->comm) {
-            std::vector<skh_ctx*> ctxs;
-            for (const Worker& w : m->w) ctxs.push_back(w.ctx);
-            if (int rc = skh_comm_init_all(ctxs.data(), (int)ctxs.size(), &m->comm)) return rc;
-        }
+        if (int rc = skh_multi_comm_init(m)) return rc;
         if (int rc = skh_stats_allreduce(m->comm, m->partials.data())) return rc;
     }
     skh_stats_merge(inout, &m->partials[0]);

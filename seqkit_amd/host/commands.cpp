@@ -54,6 +54,21 @@ struct Ctx {
         if (all.size() > 1 && skh_multi_init(all.data(), (int)all.size(), &multi) != SKH_OK) return -1;
         return 0;
     }
+    // The communicators of `stats` over several GPUs.  RCCL may announce itself on standard output while
+    // one is made, and standard output is the command's data: file descriptor 1 points at standard error
+    // meanwhile (stats prints its table after the last file: nothing else writes to it at this point).
+    int make_comms()
+    {
+        if (all.size() < 2 || comm) return 0;
+        fflush(stdout);
+        const int saved = dup(1);
+        if (saved >= 0) (void)dup2(2, 1);
+        int rc = skh_comm_init_all(all.data(), (int)all.size(), &comm);
+        if (rc == SKH_OK && multi) rc = skh_multi_comm_init(multi);
+        fflush(stdout);
+        if (saved >= 0) { (void)dup2(saved, 1); close(saved); }
+        return rc == SKH_OK ? 0 : -1;
+    }
     // SKH_SHARES=1: what every GPU did in the last skh_*_multi call, on stderr
     void report_shares(const char* what) const
     {
@@ -203,6 +218,8 @@ struct FastqNorm {
     uint64_t consumed = 0;      // bytes of the input they span
     uint64_t lines = 0;         // input lines they span
     int64_t error_line = -1;    // 0-based input line of a format violation, or -1
+    bool wrapped = false;       // some record was not in the plain four-line form (sequence or quality on several
+                                // lines or on none, blank lines before a record)
 };
 
 // text[0, n) starts between records.  final: the text ends where the file ends.  The four-line
@@ -229,8 +246,9 @@ FastqNorm normalize_fastq(const uint8_t* text, uint64_t n, bool final, std::vect
     };
     for (;;) {
         const uint64_t rec_out = out.size();
-        bool got = false;
-        while (next_line()) { if (ll) { got = true; break; } }      // blank lines between records
+        bool got = false, blank = false;
+        while (next_line()) { if (ll) { got = true; break; } blank = true; }      // blank lines between records
+        if (got && blank) r.wrapped = true;
         if (!got) {
             if (p >= n && final) { r.consumed = n; r.lines = line_no; }
             out.resize(rec_out);
@@ -239,25 +257,25 @@ FastqNorm normalize_fastq(const uint8_t* text, uint64_t n, bool final, std::vect
         if (lp[0] != '@') { r.error_line = (int64_t)line_no - 1; out.resize(rec_out); return r; }
         out.insert(out.end(), lp, lp + ll);
         out.push_back('\n');
-        uint64_t sl = 0, ql = 0;
-        bool plus = false, cut = false;
+        uint64_t sl = 0, ql = 0, seq_lines = 0, qual_lines = 0;
+        bool cut = false;
         while (true) {
             if (!next_line()) { cut = !(final && p >= n); break; }
-            if (ll && lp[0] == '+') { plus = true; break; }
+            if (ll && lp[0] == '+') break;
             out.insert(out.end(), lp, lp + ll);
-            sl += ll;
+            sl += ll; seq_lines++;
         }
         if (cut) { out.resize(rec_out); return r; }
         out.push_back('\n'); out.push_back('+'); out.push_back('\n');
         while (ql < sl) {
             if (!next_line()) { cut = !(final && p >= n); break; }
             out.insert(out.end(), lp, lp + ll);
-            ql += ll;
+            ql += ll; qual_lines++;
         }
         if (cut) { out.resize(rec_out); return r; }
-        (void)plus;
         if (ql != sl) { r.error_line = (int64_t)line_no - 1; out.resize(rec_out); return r; }
         out.push_back('\n');
+        if (seq_lines != 1 || qual_lines != 1) r.wrapped = true;
         r.nrec++; r.consumed = p; r.lines = line_no;
     }
 }
@@ -327,6 +345,7 @@ public:
                 if (have_ < cap && !eof_) continue;                        // top the block up again
             }
             PhaseTimer pt(1);
+            const bool was_multiline = multiline_;
             if (!multiline_) {
                 if (skh_text_parse(ctx_, t_, have_, fastq_ ? SKH_FASTQ : SKH_FASTA, eof_, &res) != SKH_OK) {
                     err_ = skh_last_error();
@@ -344,6 +363,12 @@ public:
                 // wrapped FASTQ records: the block's text is kept aside, its four-line form is parsed
                 orig_.assign(buf, buf + have_);
                 const FastqNorm nr = normalize_fastq(orig_.data(), have_, eof_, norm_);
+                if (!was_multiline && !nr.wrapped && res.status == SKH_PARSE_EFORMAT) {
+                    // plain four-line text as far as the serial scan got: the GPU parser's finding stands
+                    err_ = "error when parsing " + path_ + ": invalid FASTA/Q format near line " +
+                           std::to_string(lines_before_ + (uint64_t)res.error_line + 1);
+                    return false;
+                }
                 if (nr.error_line >= 0) {
                     err_ = "error when parsing " + path_ + ": invalid FASTA/Q format near line " +
                            std::to_string(lines_before_ + (uint64_t)nr.error_line + 1);
@@ -702,6 +727,7 @@ private:
                 continue;
             }
             skh_parse_result res;
+            bool rewrite = multiline;                // this block goes through normalize_fastq
             if (!multiline) {
                 PhaseTimer pt(1);
                 if (skh_text_parse_at(b->ctx, b->t, off, have, s.fastq ? SKH_FASTQ : SKH_FASTA, eof, &res) != SKH_OK) {
@@ -712,11 +738,18 @@ private:
                 // four-line record for the GPU parser either: blank lines between records are the serial
                 // scan's business too.
                 if (s.fastq && (res.status == SKH_PARSE_EFORMAT ||
-                                (res.nrec == 0 && (buf[off] == '\n' || buf[off] == '\r')))) multiline = true;
+                                (res.nrec == 0 && (buf[off] == '\n' || buf[off] == '\r')))) rewrite = true;
             }
             uint64_t consumed = 0, lines = 0;
-            if (multiline) {
+            if (rewrite) {
                 const FastqNorm nr = normalize_fastq(buf + off, have, eof, norm);
+                if (!multiline && !nr.wrapped && res.status == SKH_PARSE_EFORMAT) {
+                    // plain four-line text as far as the serial scan got: the GPU parser's finding stands, a
+                    // malformed record does not send the rest of the file through the serial rewrite
+                    s.fail("error when parsing " + s.path + ": invalid FASTA/Q format near line " +
+                           std::to_string(lines_before + (uint64_t)res.error_line + 1));
+                    break;
+                }
                 if (nr.error_line >= 0 || (eof && nr.consumed != have)) {
                     s.fail("error when parsing " + s.path + ": invalid FASTA/Q format near line " +
                            std::to_string(lines_before + (uint64_t)(nr.error_line >= 0 ? nr.error_line : (int64_t)nr.lines) + 1));
@@ -724,9 +757,12 @@ private:
                 }
                 if (nr.nrec == 0) {
                     if (eof) break;
+                    multiline = true;
                     acc = b; acc_off = off; acc_have = have;       // not one whole record yet: more text is needed
                     continue;
                 }
+                // the blocks after one that was four-line text throughout go back to the GPU parser
+                multiline = nr.wrapped;
                 consumed = nr.consumed; lines = nr.lines;
             } else {
                 if (res.status == SKH_PARSE_EFORMAT) {
@@ -749,7 +785,7 @@ private:
                 tail.resize(keep);
                 copy_bytes(tail.data(), buf + off + consumed, keep);
             }
-            if (multiline) {
+            if (rewrite) {
                 // the four-line form of the block's records takes the place of its text and is parsed
                 if (norm.size() > b->cap) {                        // (records without any sequence line grow by two bytes)
                     Block* nb = replace_block(s, b, 2 * norm.size());
@@ -1704,7 +1740,7 @@ int cmd_stats(const GlobalOpts& g, const StatsOpts& o, const std::vector<std::st
             if (!tb.error().empty()) return fatal(tb.error());
             if (part.size() > 1) {
                 // the path's one collective: the per-GPU totals all-reduced over RCCL (stat.go:106-125 across GPUs)
-                if (!ctx.comm && skh_comm_init_all(ctx.all.data(), (int)ctx.all.size(), &ctx.comm) != SKH_OK) return fatal(skh_last_error());
+                if (ctx.make_comms() != 0) return fatal(skh_last_error());
                 if (skh_stats_allreduce(ctx.comm, part.data()) != SKH_OK) return fatal(skh_last_error());
             }
             const skh_stats_partial tot = part[0];
@@ -1721,6 +1757,7 @@ int cmd_stats(const GlobalOpts& g, const StatsOpts& o, const std::vector<std::st
             if (first) { fastq_first = rd.is_fastq() && bt.offs()[1] > 0; first = false; }   // stat.go:107-113
             // num, len_sum, gap_sum, len_min, len_max of the batch on the GPU (stat.go:106-125)
             // (several GPUs: the batch is cut over all of them and their totals are all-reduced, skh_stats_multi)
+            if (ctx.multi && ctx.make_comms() != 0) return fatal(skh_last_error());
             const int rc = ctx.multi ? skh_stats_multi(ctx.multi, bt.b, bt.nrec, is_gap, &tot)
                                      : skh_stats_reduce(ctx.c, bt.b, bt.nrec, is_gap, &tot);
             if (rc != SKH_OK) return fatal(skh_last_error());

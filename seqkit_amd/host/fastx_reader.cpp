@@ -121,7 +121,7 @@ done:
 static uint32_t id_length(const uint8_t* name, size_t n)
 {
     size_t i = 0;
-    while (i < n && !(name[i] == ' ' || (name[i] >= '\t' && name[i] <= '\r'))) i++;
+    while (i < n && !(name[i] == ' ' || (name[i] >= '\t' && name[i] <= '\r' && name[i] != '\v'))) i++;
     return (uint32_t)(i == 0 ? n : i);
 }
 

@@ -120,7 +120,7 @@ void id_span(const GlobalOpts& g, const uint8_t* name, uint32_t n, uint32_t* off
     if (!g.id_re) {
         // `^([^\s]+)\s?`: up to the first white space; no match (empty, or starts with white space): the whole line
         uint32_t i = 0;
-        while (i < n && !(name[i] == ' ' || (name[i] >= '\t' && name[i] <= '\r'))) i++;
+        while (i < n && !(name[i] == ' ' || (name[i] >= '\t' && name[i] <= '\r' && name[i] != '\v'))) i++;
         *off = 0; *len = i == 0 ? n : i;
         return;
     }

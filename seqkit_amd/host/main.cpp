@@ -200,6 +200,20 @@ int main(int argc, char** argv)
         if (g.id_regexp.find('(') == std::string::npos || g.id_regexp.find(')') == std::string::npos)
             return fatal("regular expression must contain \"(\" and \")\" to capture matched ID. default: `^([^\\s]+)\\s?`");
         if (g.host_parse) return fatal("--id-regexp / --id-ncbi are not available with --host-parse");
+        // The reference compiles the expression with Go's regexp (RE2 syntax); here it runs on std::regex
+        // (ECMAScript).  What the two spell differently is refused rather than matched differently:
+        // inline flags and named groups "(?i)", "(?P<name>", and the escapes \p \P \z \Q \C.
+        for (size_t i = 0; i + 1 < g.id_regexp.size(); i++) {
+            const char a = g.id_regexp[i], b = g.id_regexp[i + 1];
+            const bool flags = a == '(' && b == '?' && i + 2 < g.id_regexp.size() && g.id_regexp[i + 2] != ':' &&
+                               g.id_regexp[i + 2] != '=' && g.id_regexp[i + 2] != '!' && (i == 0 || g.id_regexp[i - 1] != '\\');
+            const bool esc = a == '\\' && (b == 'p' || b == 'P' || b == 'z' || b == 'Q' || b == 'C');
+            if (esc) { i++; }
+            if (flags || esc)
+                return fatal("error parsing regexp: RE2-only syntax (inline flags, named groups, \\p \\P \\z \\Q \\C) is not supported "
+                             "by --id-regexp here");
+            if (a == '\\') i++;                      // an escaped character is not the start of anything
+        }
         try { g.id_re = std::make_shared<std::regex>(g.id_regexp, std::regex::ECMAScript | std::regex::optimize); }
         catch (const std::regex_error& e) { return fatal(std::string("error parsing regexp: ") + e.what()); }
     }

@@ -32,7 +32,7 @@ int fail(int code, const char* msg) { g_err = msg; return code; }
 uint32_t id_length(const uint8_t* name, uint32_t n)
 {
     uint32_t i = 0;
-    while (i < n && !(name[i] == ' ' || (name[i] >= '\t' && name[i] <= '\r'))) i++;
+    while (i < n && !(name[i] == ' ' || (name[i] >= '\t' && name[i] <= '\r' && name[i] != '\v'))) i++;
     return i == 0 ? n : i;
 }
 
@@ -724,6 +724,13 @@ int skh_comm_init_rank(skh_ctx* ctx, const uint8_t*, int nranks, int rank, skh_c
 }
 void skh_comm_destroy(skh_comm* c) { delete c; }
 int skh_comm_local_ranks(const skh_comm* c) { return c ? (int)c->ctx.size() : 0; }
+int skh_comm_rccl_version(int* runtime_version, int* header_version, int* shared_with_process)
+{
+    if (runtime_version) *runtime_version = 0;
+    if (header_version) *header_version = 0;
+    if (shared_with_process) *shared_with_process = 0;
+    return SKH_OK;
+}
 int skh_stats_allreduce(skh_comm* c, skh_stats_partial* partials)
 {
     if (!c || !partials) return fail(SKH_EINVAL, "NULL argument");
@@ -821,6 +828,7 @@ int skh_multi_init(skh_ctx* const* ctxs, int n, skh_multi** out)
 }
 void skh_multi_destroy(skh_multi* m) { delete m; }
 int skh_multi_size(const skh_multi* m) { return m ? (int)m->ctx.size() : 0; }
+int skh_multi_comm_init(skh_multi* m) { return m ? SKH_OK : fail(SKH_EINVAL, "multi is NULL"); }
 int skh_multi_shares(const skh_multi* m, skh_share_info* info)
 {
     if (!m || !info) return fail(SKH_EINVAL, "NULL argument");

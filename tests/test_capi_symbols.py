@@ -71,3 +71,35 @@ def test_init_without_gpu_fails_loudly(lib):
     ctx = C.c_void_p()
     assert lib.skh_init(0, C.byref(ctx)) == -2
     assert b"device" in lib.skh_last_error().lower()
+
+
+def test_rccl_already_in_the_process_is_the_one_used(lib, tmp_path):
+    """A process that already holds RCCL symbols (torch.distributed, a static link) must be given that copy,
+    not a second one: a stand-in library with the nine entry points is loaded into the global scope first,
+    and the library reports its version and that it did not open anything itself."""
+    import subprocess
+    import sys
+    src = tmp_path / "fake_rccl.c"
+    src.write_text("""
+        int ncclGetVersion(int *v) { *v = 99999; return 0; }
+        int ncclGetUniqueId(void *a) { return 1; }
+        int ncclCommInitRank(void *a, int n, void *id, int r) { return 1; }
+        int ncclCommInitAll(void *a, int n, const int *d) { return 1; }
+        int ncclCommDestroy(void *a) { return 0; }
+        int ncclAllReduce(const void *a, void *b, unsigned long n, int t, int o, void *c, void *s) { return 1; }
+        int ncclGroupStart(void) { return 0; }
+        int ncclGroupEnd(void) { return 0; }
+        const char *ncclGetErrorString(int r) { return "stand-in"; }
+    """)
+    so = tmp_path / "libfake_rccl.so"
+    subprocess.check_call(["gcc", "-shared", "-fPIC", "-o", str(so), str(src)])
+    code = ("import ctypes as C, sys\n"
+            "sys.path.insert(0, %r)\n"
+            "C.CDLL(%r, mode=C.RTLD_GLOBAL)\n"
+            "from seqkit_amd import load\n"
+            "lib = load()\n"
+            "v = [C.c_int(-1), C.c_int(-1), C.c_int(-1)]\n"
+            "rc = lib.skh_comm_rccl_version(C.byref(v[0]), C.byref(v[1]), C.byref(v[2]))\n"
+            "print(rc, v[0].value, v[1].value > 0, v[2].value)\n" % (ROOT, str(so)))
+    out = subprocess.check_output([sys.executable, "-c", code]).decode().split()
+    assert out == ["0", "99999", "True", "1"], out

@@ -212,5 +212,31 @@ def test_custom_id_regexp(san, oracle_cli, tmp_path):
         for extra in ([], ["--batch-bytes", "8192"]):
             got = clean(run_cli(san["asan"], argv + extra + [f]))
             assert got[0] == want[0] == 0 and got[1] == want[1], (argv, extra)
+    # \s of the default expression is Go's [\t\n\f\r ]: a vertical tab belongs to the ID
+    vt = tmp_path / "vt.fa"
+    vt.write_bytes(b">ab\x0bcd ef\nACGT\n>x\x0cy z\nAC\n")
+    for argv in (["seq", "-n", "-i"], ["fx2tab", "-n", "-i"]):
+        got = clean(run_cli(san["asan"], argv + [str(vt)]))
+        assert got[1] == run_cli(oracle_cli, argv + [str(vt)])[1] and got[1].startswith(b"ab\x0bcd") and b"\nx" in got[1] and b"x\x0cy" not in got[1]
     rc, _, err = run_cli(san["asan"], ["seq", "-n", "-i", "--id-regexp", "abc", "contigs.fa"])
     assert rc == 255 and b"regular expression must contain" in err
+
+
+def test_malformed_record_in_a_four_line_file_is_an_error_not_a_mode_switch(san, oracle_cli, tmp_path):
+    # a quality line one byte short, far into a plain four-line file: the parse error names that record's
+    # lines (the serial multi-line scan is for wrapped records only), whatever the block size
+    import gzip
+    with gzip.open(os.path.join(GOLDEN, "reads_1.fq.gz"), "rb") as fh:
+        lines = fh.read().split(b"\n")
+    bad = 4 * 1800 + 3
+    lines[bad] = lines[bad][:-1]
+    f = tmp_path / "short_quality.fq"
+    f.write_bytes(b"\n".join(lines))
+    assert run_cli(oracle_cli, ["seq", str(f)])[0] == 255
+    for extra in ([], ["--batch-bytes", "20000"], ["--batch-bytes", "20000", "--gpus", "2"]):
+        os.environ["SKH_STUB_DEVICES"] = "2"
+        rc, out, err = clean(run_cli(san["asan"], ["seq", "-r", "-p"] + extra + [str(f)]))
+        assert rc == 255 and b"[ERRO]" in err and b"invalid FASTA/Q format near line" in err, err
+        n = int(err.decode().rsplit("near line", 1)[1].split()[0])
+        assert bad - 3 <= n - 1 <= bad + 2, (n, bad)
+    os.environ.pop("SKH_STUB_DEVICES", None)

@@ -552,3 +552,15 @@ def test_custom_id_regexp(cli, oracle_cli, tmp_path):
             got = run_cli(cli, argv + extra + [f])
             assert got[0] == want[0] == 0 and got[1] == want[1], (argv, extra)
 
+
+
+def test_id_white_space_is_go_white_space(cli, oracle_cli, tmp_path):
+    # \s of the default `^([^\s]+)\s?` is Go's [\t\n\f\r ]: a vertical tab belongs to the ID, a form feed ends it
+    # (no reference-held vector has such a head line: the rule is RE2's documented class)
+    vt = tmp_path / "vt.fa"
+    vt.write_bytes(b">ab\x0bcd ef\nACGT\n>x\x0cy z\nAC\n")
+    for argv in (["seq", "-n", "-i"], ["fx2tab", "-n", "-i"], ["seq", "-i", "-r"]):
+        for mode in ([], ["--host-parse"]):
+            got = run_cli(cli, argv + mode + [str(vt)])
+            assert got[0] == 0 and got[1] == run_cli(oracle_cli, argv + [str(vt)])[1]
+            assert b"ab\x0bcd" in got[1] and b"x\x0cy" not in got[1]
