@@ -90,6 +90,11 @@ skh::LaunchCfg skh::cfg_for(const skh_ctx* ctx, uint64_t nrec, uint64_t total)
     // lengths (57.5 / 61), whose records beyond the stage it writes straight to global memory.
     c.flat = ctx->staged >= 0 ? (ctx->staged == 2) : (mean_len < 128 || (mean_len >= 192 && mean_len < 3000));
     c.flat_steps = ctx->staged_steps;
+    // in place, long records: tiles per workgroup run.  Measured (% of HBM peak, runs of 1 / 2 / 4 tiles): 24
+    // chromosomes 65 / 63 / 61, short reads with 200 contigs among them 51 / 50 / 49, nanopore-like reads (too many
+    // long records for the launch's list: every run searches and walks the offsets) 56 / 59 / 60.  A batch of at
+    // most LONG_LIST records is sure to have its long records listed: one tile; otherwise two.
+    c.inplace_run = ctx->inplace_run >= 0 ? ctx->inplace_run : (nrec <= skh::LONG_LIST ? 0 : 1);
     // in place the flat kernel is ahead or level at every mean length (% of HBM peak against the staged /
     // window-pair kernels: 100 bases 60 / 51, 150: 59 / 58, 250: 61.5 / 59, 30-151: 48 / 40, 500 +- 100: 60 / 46,
     // 1000 +- 200: 61 / 50, 4000 +- 800: 59 / 57, 6000 +- 1200: 63 / 58, 10000 +- 2000: 64 / 59, nanopore-like
@@ -191,6 +196,8 @@ int skh_init(int device, skh_ctx** out)
     c->use_hint = env_int("SKH_HINT", 1);
     c->staged = env_int("SKH_STAGED", -1);
     c->staged_steps = (uint32_t)env_int("SKH_STAGED_STEPS", 0);
+    c->inplace_run = env_int("SKH_INPLACE_RUN", -1);
+    if (c->inplace_run > 2) c->inplace_run = -1;
     c->short_steps = (uint32_t)env_int("SKH_SHORT_STEPS", 0);
     c->count_steps = (uint32_t)env_int("SKH_COUNT_STEPS", 0);
     c->count_u = env_int("SKH_COUNT_U", 0);
@@ -356,9 +363,9 @@ static int revcomp_impl(skh_ctx* ctx, const uint8_t* d_in, uint8_t* d_out, const
         skh::BatchHint h;
         HIP_TRY(hipStreamSynchronize(st));
         HIP_TRY(hipMemcpy(&h, ctx->d_hints + slot, sizeof h, hipMemcpyDeviceToHost));
-        if (h.pad[0] != 0)
+        if (h.stage_check != 0)
             return fail(SKH_EHIP, "staged reverse kernel: %s wavefront steps found their stage buffer incomplete",
-                        std::to_string(h.pad[0]).c_str());
+                        std::to_string(h.stage_check).c_str());
 #endif
     } else {
         if (lut) HIP_TRY(skh::launch_map_plane(cfg, d_in, d_out, total, t, st));

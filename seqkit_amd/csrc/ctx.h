@@ -24,6 +24,7 @@ struct skh_ctx {
     int use_hint = 1;
     int staged = -1;         // -1: by mean record length
     uint32_t staged_steps = 0;
+    int inplace_run = -1;    // log2 of the tiles per workgroup run of k_reverse_inplace_long (-1: by the number of records)
     uint32_t short_steps = 0;
     uint32_t count_steps = 0;
     int count_u = 0;         // chunks per lane and round of the counting kernel (0: from the mean record length)

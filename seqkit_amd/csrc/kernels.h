@@ -25,6 +25,7 @@ struct LaunchCfg {
     int flat;            // reverse out of place: 1 = the flat kernel (pieces of all records of a step dealt over the lanes)
                          // instead of either
     int flat_inplace;    // the same choice for the in-place form
+    int inplace_run;     // in place, long records: log2 of the 32-KiB tiles per workgroup run (0, 1 or 2)
     uint32_t staged_steps;   // staged kernel: steps per wavefront (0 = default)
     uint32_t flat_steps;     // flat kernel: steps per wavefront (0 = default)
     uint32_t short_steps;    // direct reverse kernel: steps per wavefront (0 = about 32 KiB of plane per workgroup)
@@ -35,12 +36,18 @@ struct LaunchCfg {
 };
 
 // What a launch learns about its batch on the device, in one small pass before the kernels proper
-// (launch_prepare): 16 bytes of device scratch per launch in flight.
+// (launch_prepare): 12 KiB of device scratch per launch in flight.
+constexpr uint32_t LONG_LIST = 512;      // long records a launch can list; with more of them the long-record kernels walk the offsets
+struct LongRec { uint64_t s, e, rec; }; // plane range and index of a record longer than SKH_LONG_T
 struct BatchHint {
     uint32_t n_long;       // records longer than SKH_LONG_T met by the short kernel (the long-record kernel
                            // returns at once when it is 0)
     uint32_t mean_short;   // mean length of the sampled records of at most SKH_LONG_T bytes (~0u: none sampled)
-    uint32_t pad[2];
+    uint32_t stage_check;  // checked build only: wavefront steps of the staged kernel that met an incomplete stage buffer
+    uint32_t max_short;    // the longest of those sampled records
+    LongRec list[LONG_LIST];   // the first LONG_LIST of them, in no particular order: with a few long records among
+                               // millions of short ones the long-record kernels look here instead of searching and
+                               // walking the offsets of every run of the plane
 };
 
 // log2 of the lanes that serve one record in the short kernels, from a mean record length.
@@ -55,28 +62,28 @@ __host__ __device__ inline int lanes_log2_reverse(uint64_t mean)
     while (lg < 6 && (1ull << lg) < lanes) lg++;
     return lg;
 }
-// Counting kernel: a lane takes U chunks per round (all loaded before the first lookup), G = 2^k lanes serve
-// a record.  U is chosen (3, 4 or 5) so that G * U holds a record of the mean length in one round with the
-// fewest idle chunk slots: 100-base reads 2 lanes x 4 chunks, 150 bases 4 x 3, 250 bases 4 x 5.
+// Counting kernel: a lane takes U chunks per round (the loads of the slots that are in use go out before the first
+// lookup), G = 2^k lanes serve a record.  Measured on fixed and +-20 % lengths, every G x U (% of HBM peak, best / what
+// "one round with the fewest idle slots" chose before): 350 bases 4 x 5: 59 / 8 x 3: 56; 700: 8 x 5: 66 / 16 x 4: 55;
+// 1000: 8 x 5: 63-71 / 16 x 4: 58; 4000: 32 x 5: 74 / 64 x 3: 63; 150 and 250 bases as before (4 x 3: 65, 4 x 5: 62).
+// Few lanes with several rounds beat many lanes with one: a wavefront then holds more records, and what it has in
+// flight does not depend on one record's length.  So: G = chunks / 8 rounded up to a power of two (two to three
+// rounds of five chunks for records beyond 20 chunks), doubled for a short read that would miss its single round by a
+// chunk or two; U = what one round needs, between 3 and 5.
 __host__ __device__ inline int lanes_log2_count(uint64_t mean, int U)
 {
-    const uint64_t chunks = (mean + 15) / 16 + 1, lanes = (chunks + (uint64_t)U - 1) / (uint64_t)U;
-    int lg = 0;
+    (void)U;
+    const uint64_t chunks = (mean + 15) / 16 + 1, lanes = (chunks + 7) / 8;
+    int lg = 1;
     while (lg < 6 && (1ull << lg) < lanes) lg++;
+    if (chunks <= 20 && (5ull << lg) < chunks) lg++;
     return lg;
 }
 inline int count_chunks_per_lane(uint64_t mean)
 {
     const uint64_t chunks = (mean + 15) / 16 + 1;
-    if (chunks > 80) return 3;          // records of kilobytes take several rounds anyway: measured best with 3
-    int best = 3;
-    uint64_t best_waste = ~0ull;
-    for (int U = 3; U <= 5; U++) {
-        const uint64_t slots = ((uint64_t)U) << lanes_log2_count(mean, U);
-        const uint64_t waste = slots >= chunks ? slots - chunks : ~0ull - 1;      // (more than 64 lanes' worth: several rounds)
-        if (waste < best_waste) { best_waste = waste; best = U; }
-    }
-    return best;
+    const uint64_t G = 1ull << lanes_log2_count(mean, 0), u = (chunks + G - 1) / G;
+    return u < 3 ? 3 : (u > 5 ? 5 : (int)u);
 }
 
 // lut == nullptr: reverse only.  qin/qout == nullptr: no quality plane.  hint: device scratch of this

@@ -87,31 +87,34 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_prepare(const uint64_t* __restric
                                                        BatchHint* __restrict__ hint)
 {
     __shared__ unsigned long long s_sum[SKH_BLOCK / 64];
-    __shared__ uint32_t s_n[SKH_BLOCK / 64];
+    __shared__ uint32_t s_n[SKH_BLOCK / 64], s_max[SKH_BLOCK / 64];
     constexpr uint32_t PER = 4;
     const uint64_t nsample = nrec < PER * SKH_BLOCK ? nrec : PER * SKH_BLOCK;
     unsigned long long sum = 0;
-    uint32_t n = 0;
+    uint32_t n = 0, longest = 0;
 #pragma unroll
     for (uint32_t k = 0; k < PER; k++) {
         const uint64_t i = threadIdx.x + (uint64_t)k * SKH_BLOCK;
         if (i < nsample) {
             const uint64_t r = (nrec / nsample) * i + (nrec % nsample) * i / nsample;   // = i * nrec / nsample, no overflow
             const uint64_t len = offs[r + 1] - offs[r];
-            if (len <= SKH_LONG_T) { sum += len; n++; }
+            if (len <= SKH_LONG_T) { sum += len; n++; longest = (uint32_t)len > longest ? (uint32_t)len : longest; }
         }
     }
     for (uint32_t m = 1; m < 64; m <<= 1) {
         sum += __shfl_xor(sum, m);
         n += __shfl_xor(n, m);
+        const uint32_t t = __shfl_xor(longest, m);
+        longest = t > longest ? t : longest;
     }
-    if ((threadIdx.x & 63) == 0) { s_sum[threadIdx.x >> 6] = sum; s_n[threadIdx.x >> 6] = n; }
+    if ((threadIdx.x & 63) == 0) { s_sum[threadIdx.x >> 6] = sum; s_n[threadIdx.x >> 6] = n; s_max[threadIdx.x >> 6] = longest; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < SKH_BLOCK / 64; w++) { sum += s_sum[w]; n += s_n[w]; }
+        for (int w = 1; w < SKH_BLOCK / 64; w++) { sum += s_sum[w]; n += s_n[w]; longest = s_max[w] > longest ? s_max[w] : longest; }
         hint->n_long = 0;
         hint->mean_short = n ? (uint32_t)(sum / n) : ~0u;
-        hint->pad[0] = hint->pad[1] = 0;
+        hint->stage_check = 0;
+        hint->max_short = longest;
     }
 }
 
@@ -143,10 +146,45 @@ struct WalkLds {
     uint32_t first;
 };
 
+// a short kernel met record `rec` = [s, e), which it leaves to the long-record kernel of its launch
+__device__ __forceinline__ void note_long(BatchHint* __restrict__ hint, uint64_t rec, uint64_t s, uint64_t e)
+{
+    const uint32_t k = atomicAdd(&hint->n_long, 1u);
+    if (k < LONG_LIST) { hint->list[k].s = s; hint->list[k].e = e; hint->list[k].rec = rec; }
+}
+
 template <typename F>
 __device__ __forceinline__ void for_each_long(const uint64_t* __restrict__ offs, uint64_t nrec, uint64_t t0,
-                                              uint64_t t1, WalkLds& W, F&& f)
+                                              uint64_t t1, WalkLds& W, const BatchHint* __restrict__ hint, F&& f)
 {
+    const uint32_t n_listed = hint->n_long;              // the same in every thread (the short kernel has finished)
+    if (n_listed <= LONG_LIST) {
+        // every long record of the batch is in the launch's list: the ones that overlap the run are picked
+        // out of it (a run of LONG_RUN bytes meets at most LONG_RUN / LONG_T + 2 of them), sorted by position
+        constexpr uint32_t MAXM = 16;
+        __syncthreads();
+        if (threadIdx.x == 0) W.first = 0;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < n_listed; i += SKH_BLOCK) {
+            const LongRec lr = hint->list[i];
+            if (lr.s < t1 && lr.e > t0) {
+                const uint32_t k = atomicAdd(&W.first, 1u);
+                if (k < MAXM) { W.off[3 * k] = lr.s; W.off[3 * k + 1] = lr.e; W.off[3 * k + 2] = lr.rec; }
+            }
+        }
+        __syncthreads();
+        const uint32_t m = W.first;
+        if (m <= MAXM) {
+            if (threadIdx.x == 0)
+                for (uint32_t a = 1; a < m; a++)
+                    for (uint32_t b = a; b > 0 && W.off[3 * b] < W.off[3 * b - 3]; b--)
+                        for (uint32_t c = 0; c < 3; c++) { const uint64_t t = W.off[3 * b + c]; W.off[3 * b + c] = W.off[3 * b - 3 + c]; W.off[3 * b - 3 + c] = t; }
+            __syncthreads();
+            for (uint32_t k = 0; k < m; k++) f(W.off[3 * k + 2], W.off[3 * k], W.off[3 * k + 1]);
+            return;
+        }
+        // (more matches than a run can meet: the list holds a record more than once -- walk instead)
+    }
     uint64_t r = find_record(offs, nrec, t0);            // the same in every wavefront
     while (true) {
         __syncthreads();                                  // the slice of the iteration before is done with
@@ -424,7 +462,6 @@ template <bool COMP, bool FASTQ>
 __global__ __launch_bounds__(SKH_BLOCK) void k_reverse_short(RevPlanes P, uint64_t nrec, Table256 lut, int logG_host,
                                                              uint32_t steps, BatchHint* __restrict__ hint, int use_hint)
 {
-    uint32_t* n_long = &hint->n_long;
     __shared__ RevLds L;
     const uint32_t mean_short = hint->mean_short;
     rev_lds_init<COMP>(L, lut);
@@ -450,7 +487,7 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_reverse_short(RevPlanes P, uint64
         const uint64_t sprev = wo.get(g, GW), s = wo.get(g + 1, GW), e = wo.get(g + 2, GW);
         const uint64_t len = rec < rec_end ? e - s : 0;
         if (len > SKH_LONG_T) {
-            if (j == 0) atomicAdd(n_long, 1u);
+            if (j == 0) note_long(hint, rec, s, e);
         } else if (len != 0) {
             const uint64_t o0 = s & ~15ull;
             const uint32_t n_own = (uint32_t)((e - o0) >> 4);       // chunks that end inside the record
@@ -632,15 +669,13 @@ __device__ __forceinline__ uint4 lds_window_reversed(const uint8_t* slot, uint32
 }
 
 template <bool COMP, bool INPLACE>
-__global__ __launch_bounds__(SKH_BLOCK) void k_reverse_staged(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
-                                                              const uint64_t* __restrict__ offs, uint64_t total,
-                                                              uint64_t nrec, Table256 lut, int logG_host, uint32_t steps,
-                                                              BatchHint* __restrict__ hint, int use_hint)
+__device__ __forceinline__ void reverse_staged(StageLds& S, const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+                                               const uint64_t* __restrict__ offs, uint64_t total, uint64_t nrec,
+                                               const Table256& lut, int logG_host, uint32_t steps,
+                                               BatchHint* __restrict__ hint, int use_hint)
 {
-    __shared__ StageLds S;
     const uint32_t mean_short = hint->mean_short;        // asked for before the table set-up, needed after it
     rev_lds_init<COMP>(S.tab, lut);
-    uint32_t* n_long = &hint->n_long;
     const int logG = hinted_logG<false>(logG_host, mean_short, use_hint);
     const uint32_t G = 1u << logG, j = threadIdx.x & (G - 1);
     const uint32_t lane = threadIdx.x & 63, GW = 64u >> logG, g = lane >> logG;
@@ -775,12 +810,12 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_reverse_staged(const uint8_t* __r
             }
             if (lane < nof && ob + lane < nrec) bad |= staged_off0 != offs[ob + lane];
             if (lane + 64 < nof && ob + lane + 64 < nrec) bad |= staged_off1 != offs[ob + lane + 64];
-            if (bad) atomicAdd(&hint->pad[0], 1u);
+            if (bad) atomicAdd(&hint->stage_check, 1u);
         }
 #endif
         const uint64_t len = e - s;
         const bool is_long = len > SKH_LONG_T;
-        if (is_long && j == 0) atomicAdd(n_long, 1u);
+        if (is_long && j == 0) note_long(hint, rec, s, e);
         const bool work = !is_long && len != 0;
         const uint64_t o0 = s & ~15ull;
         const uint32_t n_own = work ? (uint32_t)((e - o0) >> 4) : 0u;   // chunks that end inside the record
@@ -912,6 +947,16 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_reverse_staged(const uint8_t* __r
     wait_vmcnt<0>();     // nothing may land in LDS after the wavefront has gone
 }
 
+template <bool COMP, bool INPLACE>
+__global__ __launch_bounds__(SKH_BLOCK) void k_reverse_staged(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                              const uint64_t* __restrict__ offs, uint64_t total,
+                                                              uint64_t nrec, Table256 lut, int logG_host, uint32_t steps,
+                                                              BatchHint* __restrict__ hint, int use_hint)
+{
+    __shared__ StageLds S;
+    reverse_staged<COMP, INPLACE>(S, in, out, offs, total, nrec, lut, logG_host, steps, hint, use_hint);
+}
+
 // Long records: one aligned run of LONG_RUN bytes of the plane per workgroup (see for_each_long).
 // ------------------------------------------------------------------ reverse, flat form
 //
@@ -942,14 +987,20 @@ __device__ __forceinline__ uint64_t shfl64u(uint64_t v, uint32_t src_lane)
 // INPLACE: in == out.  A step reads and writes the bytes of its own records only, and all its loads have landed
 // in the stage before its first store, so the staged steps are the same; a step that does not fit the stage
 // reverses its records by window pairs, and records beyond SKH_LONG_T are left whole to k_reverse_inplace_long.
+struct FlatLds {
+    __attribute__((aligned(16))) uint8_t stage[SKH_BLOCK / 64][RF_STAGE + 32];
+    uint8_t owner[SKH_BLOCK / 64][RF_STAGE / 16 + 64];       // a stage holds RF_STAGE / 16 whole pieces + one partial per record
+    uint8_t lut[256];
+};
+
 template <bool COMP, bool INPLACE>
-__device__ __forceinline__ void reverse_flat(const uint8_t* in, uint8_t* out, const uint64_t* __restrict__ offs, uint64_t total,
+__device__ __forceinline__ void reverse_flat(FlatLds& F, const uint8_t* in, uint8_t* out, const uint64_t* __restrict__ offs, uint64_t total,
                                              uint64_t nrec, const Table256& lut, uint32_t steps, BatchHint* __restrict__ hint,
                                              int use_hint)
 {
-    __shared__ uint8_t s_lut[256];
-    __shared__ __attribute__((aligned(16))) uint8_t s_stage[SKH_BLOCK / 64][RF_STAGE + 32];
-    __shared__ uint8_t s_owner[SKH_BLOCK / 64][RF_STAGE / 16 + 64];       // a stage holds RF_STAGE / 16 whole pieces + one partial per record
+    uint8_t* s_lut = F.lut;
+    auto& s_stage = F.stage;
+    auto& s_owner = F.owner;
     static_assert(SKH_BLOCK == 256, "one table byte per thread");
     s_lut[threadIdx.x] = lut.v[threadIdx.x];
     __syncthreads();
@@ -988,41 +1039,53 @@ __device__ __forceinline__ void reverse_flat(const uint8_t* in, uint8_t* out, co
         if (p1 == p0) continue;
         const uint64_t a0 = p0 & ~15ull;
         if (p1 - a0 > RF_STAGE) {                        // wave-uniform: record by record, straight to global memory
-            for (uint32_t i = 0; i < cnt; i++) {
-                const uint64_t s = shfl64u(t_o, i), e = shfl64u(t_e, i);
+            // Records of kilobytes by the whole wavefront, one after the other (rounds 0 .. cnt - 1); then the short
+            // ones among them, eight at a time by groups of eight lanes.  (Most such steps are steps of short reads
+            // with ONE long record among them: served one by one, forty reads cost the wavefront forty memory round
+            // trips, and the last such wavefront of a launch ended 60 us after every other.)
+            constexpr uint32_t GROUPED = 2048;           // records up to this length go to the lane groups
+            const uint32_t rounds = cnt + ((cnt + 7) >> 3);
+#pragma unroll 1
+            for (uint32_t it = 0; it < rounds; it++) {
+                const bool grouped = it >= cnt;          // wave-uniform
+                const uint32_t i = grouped ? ((it - cnt) << 3) + (lane >> 3) : it;
+                const uint32_t j = grouped ? (lane & 7u) : lane, G = grouped ? 8u : 64u;
+                const uint64_t s = shfl64u(t_o, i & 63u), e = shfl64u(t_e, i & 63u);
+                if (i >= cnt || (e - s <= GROUPED) != grouped) continue;
                 if (e - s > SKH_LONG_T) {
                     // k_reverse_tiles writes the chunks that end inside the record: the bytes of its last, partial
                     // chunk are written here
-                    if (lane == 0) atomicAdd(&hint->n_long, 1u);
+                    if (lane == 0) note_long(hint, i0 + i, s, e);
                     if (INPLACE) continue;
                     const uint64_t x = (e & ~15ull) + lane;
                     if (x < e) { const uint8_t c = in[s + (e - 1 - x)]; out[x] = COMP ? s_lut[c] : c; }
                     continue;
                 }
                 if (INPLACE) {
-                    reverse_record_inplace<COMP>(out, s, e, lane, 64, s_lut);
+                    reverse_record_inplace<COMP>(out, s, e, j, G, s_lut);
                     continue;
                 }
                 const uint32_t len = (uint32_t)(e - s);
                 if (len < 16) {
-                    if (lane < len) { const uint8_t c = in[e - 1 - lane]; out[s + lane] = COMP ? s_lut[c] : c; }
+                    for (uint32_t bb = j; bb < len; bb += G) { const uint8_t c = in[e - 1 - bb]; out[s + bb] = COMP ? s_lut[c] : c; }
                     continue;
                 }
                 // aligned 16-byte chunks of the output (the bytes before the first whole chunk go one per lane, the
                 // end of the record as its last 16 bytes once more), the loads of four rounds ahead of the stores
                 const uint32_t head = (uint32_t)(-s) & 15u;
-                if (lane < head) { const uint8_t c = in[e - 1 - lane]; out[s + lane] = COMP ? s_lut[c] : c; }      // head < 16 <= len
+                for (uint32_t bb = j; bb < head; bb += G) { const uint8_t c = in[e - 1 - bb]; out[s + bb] = COMP ? s_lut[c] : c; }      // head < 16 <= len
                 constexpr int FU = 4;
-                for (uint32_t pb = head + lane * 16; pb < len; pb += 1024 * FU) {
+                const uint32_t row = 16 * G;
+                for (uint32_t pb = head + j * 16; pb < len; pb += row * FU) {
                     uint4 v[FU];
 #pragma unroll
                     for (int u = 0; u < FU; u++) {
-                        const uint32_t p = pb + 1024 * u, t = p + 16 <= len ? p : len - 16;
+                        const uint32_t p = pb + row * u, t = p + 16 <= len ? p : len - 16;
                         v[u] = p < len ? ldu16(in + s + (len - t - 16)) : make_uint4(0, 0, 0, 0);
                     }
 #pragma unroll
                     for (int u = 0; u < FU; u++) {
-                        const uint32_t p = pb + 1024 * u, t = p + 16 <= len ? p : len - 16;
+                        const uint32_t p = pb + row * u, t = p + 16 <= len ? p : len - 16;
                         if (p >= len) continue;
                         uint4 w = reverse16(v[u]);
                         if (COMP) w = map16(w, s_lut);
@@ -1033,6 +1096,7 @@ __device__ __forceinline__ void reverse_flat(const uint8_t* in, uint8_t* out, co
             continue;
         }
         const uint32_t t_len = (uint32_t)(t_e - t_o), d_rel = (uint32_t)(t_o - a0), s_rel = (uint32_t)(t_o - p0);
+        const uint32_t packed = t_len | (d_rel << 16), head0 = (uint32_t)(p0 - a0);     // s_rel = d_rel - head0
         const uint32_t pieces = (t_len + 15) >> 4;
         uint32_t PF = pieces;
 #pragma unroll
@@ -1078,8 +1142,9 @@ __device__ __forceinline__ void reverse_flat(const uint8_t* in, uint8_t* out, co
                     r = PF > 1 ? __umulhi(q, magic) : q;
                     k = q - r * PF;
                 }
-                const uint32_t len = (uint32_t)__shfl((int)t_len, (int)r), dr = (uint32_t)__shfl((int)d_rel, (int)r);
-                const uint32_t sr = (uint32_t)__shfl((int)s_rel, (int)r);
+                // (length and place of the record in one cross-lane read: both are below 2^16 in a step that fits the stage)
+                const uint32_t pk = (uint32_t)__shfl((int)packed, (int)r);
+                const uint32_t len = pk & 0xffffu, dr = pk >> 16, sr = dr - head0;
                 const uint32_t p = 16 * k;
                 const bool in_rec = qq < nslots && p < len;
                 act[u] = in_rec && len >= 16;
@@ -1127,7 +1192,8 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_reverse_flat(const uint8_t* __res
                                                             uint64_t nrec, Table256 lut, uint32_t steps,
                                                             BatchHint* __restrict__ hint, int use_hint)
 {
-    reverse_flat<COMP, false>(in, out, offs, total, nrec, lut, steps, hint, use_hint);
+    __shared__ FlatLds F;
+    reverse_flat<COMP, false>(F, in, out, offs, total, nrec, lut, steps, hint, use_hint);
 }
 
 template <bool COMP>
@@ -1135,7 +1201,8 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_reverse_flat_inplace(uint8_t* pla
                                                                     uint64_t total, uint64_t nrec, Table256 lut,
                                                                     uint32_t steps, BatchHint* __restrict__ hint, int use_hint)
 {
-    reverse_flat<COMP, true>(plane, plane, offs, total, nrec, lut, steps, hint, use_hint);
+    __shared__ FlatLds F;
+    reverse_flat<COMP, true>(F, plane, plane, offs, total, nrec, lut, steps, hint, use_hint);
 }
 
 template <bool COMP, bool FASTQ>
@@ -1151,7 +1218,7 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_reverse_tiles(RevPlanes P, uint64
     const uint64_t t0 = (uint64_t)blockIdx.x * LONG_RUN;
     if (t0 >= total) return;
     const uint64_t t1 = t0 + LONG_RUN;                           // exclusive, may exceed total
-    for_each_long(P.offs, nrec, t0, t1 < total ? t1 : total, W, [&](uint64_t r, uint64_t s, uint64_t e) {
+    for_each_long(P.offs, nrec, t0, t1 < total ? t1 : total, W, hint, [&](uint64_t r, uint64_t s, uint64_t e) {
         const uint64_t sprev = r ? P.offs[r - 1] : 0;
         const uint64_t o0 = s & ~15ull;
         const uint32_t n_own = (uint32_t)((e - o0) >> 4);        // < 2^28 chunks: records < 4 GiB
@@ -1178,7 +1245,6 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_reverse_inplace_short(uint8_t* __
     __shared__ RevLds L;
     const uint32_t mean_short = hint->mean_short;
     rev_lds_init<COMP>(L, lut);
-    uint32_t* n_long = &hint->n_long;
     const int logG = hinted_logG<false>(logG_host, mean_short, use_hint);
     const uint32_t G = 1u << logG, j = threadIdx.x & (G - 1);
     const uint32_t lane = threadIdx.x & 63, GW = 64u >> logG, g = lane >> logG;
@@ -1194,7 +1260,7 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_reverse_inplace_short(uint8_t* __
         const uint64_t s = wo.get(g + 1, GW), e = wo.get(g + 2, GW);
         const uint64_t len = e - s;
         if (len > SKH_LONG_T) {
-            if (j == 0) atomicAdd(n_long, 1u);
+            if (j == 0) note_long(hint, rec0 + g, s, e);
         } else {
             reverse_record_inplace<COMP>(p, s, e, j, G, L.lut);
         }
@@ -1208,7 +1274,7 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_reverse_inplace_short(uint8_t* __
 // plane (workgroups whose runs lie in the back halves of records find nothing to do).  The front
 // windows are moved to 16-byte alignment: the h = -s mod 16 bytes at either end of the record are
 // swapped byte by byte by the workgroup that holds s.
-template <bool COMP>
+template <bool COMP, uint64_t RUN>
 __global__ __launch_bounds__(SKH_BLOCK) void k_reverse_inplace_long(uint8_t* __restrict__ p,
                                                                     const uint64_t* __restrict__ offs, uint64_t total,
                                                                     uint64_t nrec, Table256 lut,
@@ -1219,10 +1285,10 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_reverse_inplace_long(uint8_t* __r
     __shared__ WalkLds W;
     rev_lds_init<COMP>(L, lut);
     constexpr int U = 4;
-    const uint64_t t0 = (uint64_t)blockIdx.x * LONG_RUN;
+    const uint64_t t0 = (uint64_t)blockIdx.x * RUN;
     if (t0 >= total) return;
-    const uint64_t t1 = t0 + LONG_RUN < total ? t0 + LONG_RUN : total;
-    for_each_long(offs, nrec, t0, t1, W, [&](uint64_t, uint64_t s, uint64_t e) {
+    const uint64_t t1 = t0 + RUN < total ? t0 + RUN : total;
+    for_each_long(offs, nrec, t0, t1, W, hint, [&](uint64_t, uint64_t s, uint64_t e) {
         const uint32_t h = (uint32_t)(-(int64_t)s) & 15u;
         const uint64_t fs = s + h, be = e - h;                      // windows cover [fs, be); fs is aligned
         const uint64_t len = be - fs;                               // > LONG_T - 30
@@ -1579,7 +1645,6 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_count_short(
     __shared__ CountLds<NW> L;
     const uint32_t mean_short = hint->mean_short;        // asked for before the table set-up, needed after it
     count_lds_init<NW>(L, cls);
-    uint32_t* n_long = &hint->n_long;
     const int logG = hinted_logG<true, U>(logG_host, mean_short, use_hint);
     const bool has_neutral = neutral < 256u;
     const uint32_t neutral4 = (neutral & 0xffu) * 0x01010101u;
@@ -1605,7 +1670,7 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_count_short(
 #pragma unroll
         for (int i = 0; i < 2 * NW; i++) acc16[i] = 0;
         if (len > SKH_LONG_T) {
-            if (j == 0) atomicAdd(n_long, 1u);      // counted by k_count_tiles; zeros written here
+            if (j == 0) note_long(hint, rec, s, e);      // counted by k_count_tiles; zeros written here
         } else if (len != 0) {
             uint32_t acc8[NW];
 #pragma unroll
@@ -1627,7 +1692,8 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_count_short(
                     for (int u = 0; u < U; u++) {            // all loads of the round before the first use:
                         const uint32_t k = kb + j + u * G;   // unconditional (a lane without a chunk re-reads
                         V[u] = ld16(seq + o0 + 16ull * (k < K ? k : 0));   // chunk 0) so they issue back to back
-                    }
+                    }                                        // (skipping the loads of a slot no lane uses on a wave-uniform
+                                                             // test: 10 points slower on reads of 100-150 bases, 6-8 beyond)
 #pragma unroll
                     for (int u = 0; u < U; u++) {
                         const uint32_t k = kb + j + u * G;
@@ -1709,7 +1775,7 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_count_tiles(
     const uint64_t t1 = t0 + LONG_RUN;
     constexpr int UB = 8;                                      // chunks per lane in flight
     static_assert(LONG_RUN / SKH_BLOCK <= 512, "16-bit fields: 64 lanes x bytes per lane must stay below 65536");
-    for_each_long(offs, nrec, t0, t1 < total ? t1 : total, W, [&](uint64_t r, uint64_t s, uint64_t e) {
+    for_each_long(offs, nrec, t0, t1 < total ? t1 : total, W, hint, [&](uint64_t r, uint64_t s, uint64_t e) {
         const uint64_t a = s & ~15ull, b = (e + 15) & ~15ull;
         const uint64_t c0 = a > t0 ? a : t0, c1 = b < t1 ? b : t1;
         uint32_t acc8[NW], acc16[2 * NW];
@@ -1774,7 +1840,6 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_letters_short(const uint8_t* __re
                                                              uint64_t total, int logG, uint32_t* __restrict__ present,
                                                              BatchHint* __restrict__ hint)
 {
-    uint32_t* n_long = &hint->n_long;
     const uint32_t G = 1u << logG, j = threadIdx.x & (G - 1);
     const uint32_t lane = threadIdx.x & 63, GW = 64u >> logG, g = lane >> logG;
     const uint64_t stride = (uint64_t)gridDim.x * (SKH_BLOCK / 64) * GW;
@@ -1788,7 +1853,7 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_letters_short(const uint8_t* __re
 #pragma unroll
         for (int i = 0; i < 8; i++) m[i] = 0;
         if (len > SKH_LONG_T) {
-            if (j == 0) atomicAdd(n_long, 1u);       // k_letters_tiles ORs into the zeros written here
+            if (j == 0) note_long(hint, rec, s, e);       // k_letters_tiles ORs into the zeros written here
         } else if (len != 0) {
             const uint64_t o0 = s & ~15ull;
             const uint32_t K = (uint32_t)((e - o0 + 15) >> 4);
@@ -1825,7 +1890,7 @@ __global__ __launch_bounds__(SKH_BLOCK) void k_letters_tiles(const uint8_t* __re
     const uint64_t t0 = (uint64_t)blockIdx.x * LONG_RUN;
     if (t0 >= total) return;
     const uint64_t t1 = t0 + LONG_RUN;
-    for_each_long(offs, nrec, t0, t1 < total ? t1 : total, W, [&](uint64_t r, uint64_t s, uint64_t e) {
+    for_each_long(offs, nrec, t0, t1 < total ? t1 : total, W, hint, [&](uint64_t r, uint64_t s, uint64_t e) {
         const uint64_t a = s & ~15ull, b = (e + 15) & ~15ull;
         const uint64_t c0 = a > t0 ? a : t0, c1 = b < t1 ? b : t1;
         uint32_t m[8];
@@ -2143,6 +2208,8 @@ static hipError_t reverse_planes(const LaunchCfg& cfg, const uint8_t* in, uint8_
         // (the long-record counter keeps counting: only "zero or not" is looked at)
         hipError_t e = reverse_planes(cfg, qin, qout, nullptr, nullptr, offs, nrec, total, nullptr, hint, st);
         if (e != hipSuccess) return e;
+        // (the short kernel of the second plane lists the long records again: from an empty list)
+        if (!cfg.span_u && (e = launch_prepare(offs, nrec, hint, st)) != hipSuccess) return e;
         fastq = false;
         qin = nullptr;
         qout = nullptr;
@@ -2202,10 +2269,16 @@ static hipError_t launch_reverse_inplace_t(const LaunchCfg& cfg, uint8_t* plane,
         hipLaunchKernelGGL((k_reverse_inplace_short<COMP>), dim3(g1), dim3(SKH_BLOCK), 0, st, plane, offs, total, nrec, lut,
                            cfg.logG, hint, cfg.use_hint);
     }
-    const uint64_t g2 = long_runs(total);
+    // a workgroup moves the window pairs whose front window lies in its run, twice the run's bytes (the host
+    // chooses the run: see cfg_for)
+    const uint64_t run = SKH_TILE << cfg.inplace_run;
+    const uint64_t g2 = (total + run - 1) / run;
     if (g2 > 0x7fffffffull) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((k_reverse_inplace_long<COMP>), dim3((uint32_t)g2), dim3(SKH_BLOCK), 0, st, plane, offs, total,
-                       nrec, lut, hint);
+    switch (cfg.inplace_run) {
+    case 0: hipLaunchKernelGGL((k_reverse_inplace_long<COMP, SKH_TILE>), dim3((uint32_t)g2), dim3(SKH_BLOCK), 0, st, plane, offs, total, nrec, lut, hint); break;
+    case 2: hipLaunchKernelGGL((k_reverse_inplace_long<COMP, 4 * SKH_TILE>), dim3((uint32_t)g2), dim3(SKH_BLOCK), 0, st, plane, offs, total, nrec, lut, hint); break;
+    default: hipLaunchKernelGGL((k_reverse_inplace_long<COMP, 2 * SKH_TILE>), dim3((uint32_t)g2), dim3(SKH_BLOCK), 0, st, plane, offs, total, nrec, lut, hint); break;
+    }
     return hipGetLastError();
 }
 

@@ -109,7 +109,7 @@ if "trim" in which:      # adapter-trimmed Illumina reads
     rng = np.random.default_rng(7)
     ok &= run("trimmed reads: uniform 30..151", rng.integers(30, 152, 8_000_000), 7)
 if "r150" in which:
-    ok &= run("fixed 150 bp", np.full(10_000_000, 150), 12)
+    ok &= run("fixed 150 bp", np.full(int(os.environ.get("R150_N", 10_000_000)), 150), 12)
 if "r100" in which:
     ok &= run("fixed 100 bp", np.full(10_000_000, 100), 8)
 if "r250" in which:
@@ -125,5 +125,12 @@ if "mixed" in which:     # short reads with a few long contigs in between
     rng = np.random.default_rng(11)
     lens = np.full(4_000_000, 150); lens[rng.integers(0, len(lens), 200)] = rng.integers(100_000, 3_000_000, 200)
     ok &= run("150 bp reads + 200 long contigs", lens, 11)
+if "kbtail" in which:    # heavy-tailed kilobase lengths: steps of the flat kernel overflow its stage now and then
+    rng = np.random.default_rng(13)
+    ok &= run("heavy-tailed log-normal around 1500 (200..30000)", np.clip(np.exp(rng.normal(np.log(1500), 0.8, 1_000_000)), 200, 30000).astype(np.int64), 13)
+if "mix12k" in which:    # nine 150-base reads to one 12-kb record
+    rng = np.random.default_rng(14)
+    lens = np.full(1_500_000, 150); lens[rng.random(len(lens)) < 0.1] = 12000
+    ok &= run("150 bp reads with 10 % records of 12 kb", lens, 14)
 lib.skh_destroy(ctx)
 sys.exit(0 if ok else 1)
