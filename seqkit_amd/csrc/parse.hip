@@ -6,7 +6,8 @@
 // batch layout of the other kernels -- sequence plane, quality plane, offsets, name spans --
 // by data-parallel passes, all of them streaming and HBM-bound:
 //
-//   1. newline index   count '\n' per 4-KiB tile, scan the tile counts, scatter positions
+//   1. newline index   per 16-KiB tile, in one pass over the text: count of '\n' and their entries, tile by tile;
+//                      scan of the tile counts
 //   2. line table      per line: start, length without trailing '\r', head flag, and the
 //                      bytes it contributes to the sequence plane
 //   3. scan            exclusive sums over lines of (contribution, head flag): a line's place
@@ -111,26 +112,90 @@ __device__ __forceinline__ uint32_t nl_count16(uint4 v)
     return 16u - other;
 }
 
-__global__ __launch_bounds__(PB) void k_nl_count(const uint8_t* __restrict__ text, uint64_t n,
-                                                 uint32_t* __restrict__ tile_count)
+// A tile's newlines as the line table wants them, in ONE pass over the text: the tile's count, and the
+// entries themselves in the tile's own stretch of a table with room for TILE entries per tile (a tile
+// cannot hold more newlines than bytes), 32 bits each: position within the tile, the CR flag and the
+// first byte of the next line.  Where an entry belongs among ALL newlines is only known after the scan of
+// the tile counts; the line table reads its entries tile by tile and does not need to know.  (Counting
+// first and scattering behind the scanned bases read the text twice.  The table is four times the size of
+// the text in address space; only the entries that exist are ever touched.)
+constexpr int NLT_POS_BITS = 14;                              // TILE = 2^14
+static_assert(TILE == (1u << NLT_POS_BITS), "tile-relative positions");
+constexpr uint32_t NLT_CR = 1u << 22;
+
+__device__ __forceinline__ uint64_t nl_entry64(uint32_t e32, uint64_t t0)
 {
-    __shared__ uint32_t s_wave[PB / 64];
-    uint32_t c = 0;
+    return (t0 + (e32 & (TILE - 1))) | ((uint64_t)((e32 >> NLT_POS_BITS) & 0xffu) << NL_NEXT_SHIFT) | ((e32 & NLT_CR) ? NL_CR : 0);
+}
+
+__global__ __launch_bounds__(PB) void k_nl_index(const uint8_t* __restrict__ text, uint64_t n,
+                                                 uint32_t* __restrict__ tile_count, uint64_t* __restrict__ tile_last,
+                                                 uint32_t* __restrict__ nl_tile)
+{
+    static_assert(NLU == 4 && PB * 16 < 65536, "four 16-bit fields");
+    __shared__ uint64_t s_wave[PB / 64];
+    __shared__ uint4 s_text[TILE / 16];                   // the tile: the bytes next to a newline are looked up here
+    const uint8_t* s_byte = reinterpret_cast<const uint8_t*>(s_text);
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t t0 = (uint64_t)blockIdx.x * TILE;
-    if (t0 + TILE <= n) {                                   // a whole tile: all loads first, no masks
+    uint32_t m[NLU];
+    {
         uint4 v[NLU];
 #pragma unroll
-        for (int u = 0; u < NLU; u++) v[u] = *reinterpret_cast<const uint4*>(text + t0 + (uint64_t)(u * PB + threadIdx.x) * 16);
+        for (int u = 0; u < NLU; u++) {
+            const uint64_t o = t0 + (uint64_t)(u * PB + threadIdx.x) * 16;
+            v[u] = o < n ? *reinterpret_cast<const uint4*>(text + o) : make_uint4(0, 0, 0, 0);
+        }
 #pragma unroll
-        for (int u = 0; u < NLU; u++) c += nl_count16(v[u]);
-    } else {
-#pragma unroll
-        for (int u = 0; u < NLU; u++)
-            c += __builtin_popcount(nl_mask_at(text, n, t0 + (uint64_t)(u * PB + threadIdx.x) * 16));
+        for (int u = 0; u < NLU; u++) {
+            const uint64_t o = t0 + (uint64_t)(u * PB + threadIdx.x) * 16;
+            s_text[u * PB + threadIdx.x] = v[u];
+            m[u] = nl_mask16(v[u]);
+            if (o + 16 > n) m[u] &= o < n ? (1u << (n - o)) - 1u : 0u;
+        }
     }
-    uint32_t total;
-    block_excl_scan(c, &total, s_wave);
-    if (threadIdx.x == 0) tile_count[blockIdx.x] = total;
+    uint64_t mine = 0;
+#pragma unroll
+    for (int u = 0; u < NLU; u++) mine |= (uint64_t)__builtin_popcount(m[u]) << (16 * u);
+    uint64_t inc = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint64_t t = ((uint64_t)(uint32_t)__shfl_up((int)(uint32_t)(inc >> 32), d) << 32) | (uint32_t)__shfl_up((int)(uint32_t)inc, d);
+        if ((int)lane >= d) inc += t;
+    }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    uint64_t before = 0, all = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < PB / 64; w++) {
+        const uint64_t x = s_wave[w];
+        if (w < wave) before += x;
+        all += x;
+    }
+    const uint64_t ex = before + inc - mine;             // per row: newlines of the row before this thread's chunk
+    uint32_t* mine_out = nl_tile + (uint64_t)blockIdx.x * TILE;
+    uint32_t run = 0;
+    const uint32_t count = (uint32_t)((all & 0xffffu) + ((all >> 16) & 0xffffu) + ((all >> 32) & 0xffffu) + ((all >> 48) & 0xffffu));
+#pragma unroll
+    for (int u = 0; u < NLU; u++) {
+        const uint64_t o = t0 + (uint64_t)(u * PB + threadIdx.x) * 16;
+        uint32_t k = run + (uint32_t)((ex >> (16 * u)) & 0xffffu);
+        uint32_t mm = m[u];
+        while (mm) {
+            const uint32_t bit = __builtin_ctz(mm);
+            mm &= mm - 1;
+            const uint64_t p = o + bit;
+            const uint32_t q = (uint32_t)(p - t0);         // the neighbours outside the tile come from memory
+            const uint32_t prev = q > 0 ? s_byte[q - 1] : (p > 0 ? text[p - 1] : 0);
+            const uint32_t next = p + 1 >= n ? 0 : (q + 1 < TILE ? s_byte[q + 1] : text[p + 1]);
+            const uint32_t e32 = q | (next << NLT_POS_BITS) | (prev == '\r' ? NLT_CR : 0u);
+            mine_out[k] = e32;
+            if (k + 1 == count) tile_last[blockIdx.x] = nl_entry64(e32, t0);
+            k++;
+        }
+        run += (uint32_t)((all >> (16 * u)) & 0xffffu);
+    }
+    if (threadIdx.x == 0) tile_count[blockIdx.x] = count;
 }
 
 // exclusive scan of ntile uint32 counts into uint64 bases by ONE workgroup; total -> *n_out.
@@ -174,77 +239,7 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(const uint32_t* __restrict_
         }
         carry += all;
     }
-    if (threadIdx.x == 0) *n_out = carry;
-}
-
-// The newlines of a tile, in text order (chunk row u, then thread), behind the tile's base.  The four
-// chunk loads of a thread go out together; the four row-wise counts are scanned at once as 16-bit fields
-// of one 64-bit word (a row holds at most PB * 16 = 4096 newlines), so the tile costs one barrier.
-__global__ __launch_bounds__(PB) void k_nl_scatter(const uint8_t* __restrict__ text, uint64_t n,
-                                                   const uint64_t* __restrict__ tile_base,
-                                                   uint64_t* __restrict__ nlpos, uint64_t max_lines)
-{
-    static_assert(NLU == 4 && PB * 16 < 65536, "four 16-bit fields");
-    __shared__ uint64_t s_wave[PB / 64];
-    __shared__ uint4 s_text[TILE / 16];                   // the tile: the bytes next to a newline are looked up here
-    const uint8_t* s_byte = reinterpret_cast<const uint8_t*>(s_text);
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint64_t t0 = (uint64_t)blockIdx.x * TILE;
-    uint64_t run = tile_base[blockIdx.x];
-    uint32_t m[NLU];
-    {
-        uint4 v[NLU];
-#pragma unroll
-        for (int u = 0; u < NLU; u++) {
-            const uint64_t o = t0 + (uint64_t)(u * PB + threadIdx.x) * 16;
-            v[u] = o < n ? *reinterpret_cast<const uint4*>(text + o) : make_uint4(0, 0, 0, 0);
-        }
-#pragma unroll
-        for (int u = 0; u < NLU; u++) {
-            const uint64_t o = t0 + (uint64_t)(u * PB + threadIdx.x) * 16;
-            s_text[u * PB + threadIdx.x] = v[u];
-            m[u] = nl_mask16(v[u]);
-            if (o + 16 > n) m[u] &= o < n ? (1u << (n - o)) - 1u : 0u;
-        }
-    }
-    uint64_t mine = 0;
-#pragma unroll
-    for (int u = 0; u < NLU; u++) mine |= (uint64_t)__builtin_popcount(m[u]) << (16 * u);
-    uint64_t inc = mine;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint64_t t = ((uint64_t)(uint32_t)__shfl_up((int)(uint32_t)(inc >> 32), d) << 32) | (uint32_t)__shfl_up((int)(uint32_t)inc, d);
-        if ((int)lane >= d) inc += t;
-    }
-    if (lane == 63) s_wave[wave] = inc;
-    __syncthreads();
-    uint64_t before = 0, all = 0;
-#pragma unroll
-    for (uint32_t w = 0; w < PB / 64; w++) {
-        const uint64_t x = s_wave[w];
-        if (w < wave) before += x;
-        all += x;
-    }
-    const uint64_t ex = before + inc - mine;             // per row: newlines of the row before this thread's chunk
-#pragma unroll
-    for (int u = 0; u < NLU; u++) {
-        const uint64_t o = t0 + (uint64_t)(u * PB + threadIdx.x) * 16;
-        uint64_t k = run + ((ex >> (16 * u)) & 0xffffu);
-        uint32_t mm = m[u];
-        while (mm) {
-            const uint32_t bit = __builtin_ctz(mm);
-            mm &= mm - 1;
-            const uint64_t p = o + bit;
-            if (k < max_lines) {
-                const uint32_t q = (uint32_t)(p - t0);     // the neighbours outside the tile come from memory
-                const uint32_t prev = q > 0 ? s_byte[q - 1] : (p > 0 ? text[p - 1] : 0);
-                const uint32_t next = p + 1 >= n ? 0 : (q + 1 < TILE ? s_byte[q + 1] : text[p + 1]);
-                nlpos[k] = p | ((uint64_t)next << NL_NEXT_SHIFT) | (prev == '\r' ? NL_CR : 0);
-            }
-            k++;
-        }
-        run += (all >> (16 * u)) & 0xffffu;
-    }
+    if (threadIdx.x == 0) { *n_out = carry; base[ntile] = carry; }
 }
 
 // ---- pass 2: line table ------------------------------------------------------------------
@@ -261,6 +256,7 @@ struct ParseState {            // device scratch shared by the passes of one cal
     uint32_t pad;
     LineSum total;             // totals of the line scan
     uint64_t nrec, seq_bytes, consumed;    // the decision
+    uint64_t nrec_cap;                     // complete records at most (known before the line scan), capped at the tables' size
 };
 
 __global__ void k_parse_init(ParseState* st, uint64_t n, int final, const uint8_t* __restrict__ text,
@@ -301,32 +297,64 @@ __device__ __forceinline__ void line_span(const uint8_t* __restrict__ text, uint
     first = len ? (i ? (uint8_t)((before >> NL_NEXT_SHIFT) & 0xff) : text[0]) : 0;
 }
 
+// the entry of the last newline before tile t (0: none): of the nearest earlier tile that has one
+__device__ __forceinline__ uint64_t newline_before_tile(uint64_t t, const uint32_t* __restrict__ tile_count,
+                                                        const uint64_t* __restrict__ tile_last)
+{
+    while (t > 0) { t--; if (tile_count[t]) return tile_last[t]; }
+    return 0;
+}
+
+constexpr uint32_t LT_TILES = 8;             // tiles of newline entries a workgroup of the line table takes at a time
+
 template <bool FASTQ>
-__global__ __launch_bounds__(PB) void k_line_table(const uint8_t* __restrict__ text, uint64_t n,
-                                                   const uint64_t* __restrict__ nlpos, ParseState* st,
+__global__ __launch_bounds__(PB) void k_line_table(const uint8_t* __restrict__ text, uint64_t n, uint64_t ntile,
+                                                   const uint32_t* __restrict__ nl_tile, const uint32_t* __restrict__ tile_count,
+                                                   const uint64_t* __restrict__ tile_base, const uint64_t* __restrict__ tile_last,
+                                                   ParseState* st, uint64_t* __restrict__ nlpos,
                                                    uint64_t* __restrict__ line_start, uint32_t* __restrict__ line_len,
                                                    uint8_t* __restrict__ line_head)
 {
+    __shared__ uint64_t s_base[LT_TILES + 1], s_before[LT_TILES];
     const uint64_t nlines = st->nlines, n_nl = st->n_nl;
     // per thread, then per wavefront, then one atomic each: the flags of the whole text
     unsigned long long err = ~0ull, blank_head = ~0ull, last = 0;
     bool any = false;
-    constexpr int LU = 4;                                 // lines per thread in flight
-    const uint64_t stride = (uint64_t)gridDim.x * PB;
-    for (uint64_t i0 = (uint64_t)blockIdx.x * PB + threadIdx.x; i0 < nlines; i0 += LU * stride) {
-        uint64_t e_before[LU], e_here[LU];
-#pragma unroll
-        for (int k = 0; k < LU; k++) {
-            const uint64_t i = i0 + k * stride;
-            e_before[k] = (i != 0 && i < nlines) ? nlpos[i - 1] : 0;
-            e_here[k] = i < n_nl ? nlpos[i] : 0;
+    // Line i ends at newline i.  The newlines are read from where k_nl_index left them, tile by tile (entry k of
+    // tile t is newline tile_base[t] + k), LT_TILES tiles at a time: the lines of such a group are consecutive, a
+    // thread finds the tile of its line among the group's bases.  They leave as the dense table of 64-bit entries
+    // the later passes look lines up in.  The unterminated last line, if any, is line n_nl.
+    const uint64_t ngroup = (ntile + LT_TILES - 1) / LT_TILES;
+    for (uint64_t g = blockIdx.x; g <= ngroup; g += gridDim.x) {
+        const uint64_t T0 = g * LT_TILES;
+        __syncthreads();
+        if (threadIdx.x <= LT_TILES) { const uint64_t t = T0 + threadIdx.x; s_base[threadIdx.x] = tile_base[t < ntile ? t : ntile]; }
+        // (the newline before a tile's first: looked up once per tile here, not by the thread of that line inside the loop)
+        if (threadIdx.x >= 64 && threadIdx.x < 64 + LT_TILES) {
+            const uint64_t t = T0 + (threadIdx.x - 64);
+            s_before[threadIdx.x - 64] = newline_before_tile(t < ntile ? t : ntile, tile_count, tile_last);
         }
+        __syncthreads();
+        uint64_t i_lo = s_base[0], i_hi = s_base[LT_TILES];
+        if (g == ngroup) { i_lo = n_nl; i_hi = nlines > n_nl ? n_nl + 1 : n_nl; }     // the line without a newline
+        if (i_hi > nlines) i_hi = nlines;
+        for (uint64_t i = i_lo + threadIdx.x; i < i_hi; i += PB) {
+            uint64_t e_here = 0, e_before;
+            if (i < n_nl) {
+                uint32_t w = 0;
 #pragma unroll
-        for (int k = 0; k < LU; k++) {
-            const uint64_t i = i0 + k * stride;
-            if (i >= nlines) break;
+                for (uint32_t x = 1; x < LT_TILES; x++) w += s_base[x] <= i ? 1u : 0u;      // tile T0 + w holds newline i
+                const uint64_t t = T0 + w, t0 = t * TILE;
+                const uint32_t k = (uint32_t)(i - s_base[w]);
+                const uint32_t* ent = nl_tile + t * TILE;
+                e_here = nl_entry64(ent[k], t0);
+                e_before = k ? nl_entry64(ent[k - 1], t0) : s_before[w];
+                nlpos[i] = e_here;
+            } else {
+                e_before = s_before[0];                      // (T0 >= ntile here: every slot holds the text's last newline)
+            }
             uint64_t ls; uint32_t len; uint8_t c;
-            line_span(text, n, e_before[k], e_here[k], n_nl, i, ls, len, c);
+            line_span(text, n, e_before, e_here, n_nl, i, ls, len, c);
             bool head, bad = false;
             if (!FASTQ) {
                 head = c == '>';
@@ -340,7 +368,7 @@ __global__ __launch_bounds__(PB) void k_line_table(const uint8_t* __restrict__ t
                     bad = c != '+';
                 }                                            // role 3 (equal lengths) is checked by k_line_partials
             }
-            if (len) { last = i; any = true; }            // i grows within a thread
+            if (len) { last = i > last ? i : last; any = true; }
             if (len > LONG_LINE) atomicAdd(&st->n_long, 1u);
             if (bad && i < err) err = i;
             line_start[i] = ls;
@@ -454,7 +482,9 @@ __global__ __launch_bounds__(PB) void k_line_partials(const uint32_t* __restrict
 // Exclusive scan of the workgroup sums, in place, by one workgroup: rounds of 1024 consecutive entries
 // (one per thread, the next round's entry loaded before this round is scanned), a shuffle scan per
 // wavefront, the 16 wavefront totals through LDS, the running total carried in registers.
-__global__ __launch_bounds__(1024) void k_scan_partials(LineSum* __restrict__ part, uint64_t npart, ParseState* st)
+template <bool FASTQ>
+__global__ __launch_bounds__(1024) void k_scan_partials(LineSum* __restrict__ part, uint64_t npart, ParseState* st, int final,
+                                                        uint64_t max_records)
 {
     __shared__ uint64_t s_b[16];
     __shared__ uint32_t s_h[16];
@@ -484,14 +514,34 @@ __global__ __launch_bounds__(1024) void k_scan_partials(LineSum* __restrict__ pa
         if (i < npart) { part[i].bytes = rb; part[i].heads = rh; }
         __syncthreads();                                  // the totals are rewritten in the next round
     }
-    if (threadIdx.x == 0) { st->total.bytes = cb; st->total.heads = ch; }
+    if (threadIdx.x == 0) {
+        st->total.bytes = cb; st->total.heads = ch;
+        // the records k_parse_decide will settle on, or more (it may find a format error and settle on none): FASTA
+        // all head lines, but the last one's record when the text goes on; FASTQ the whole groups of four lines
+        // before the first blank head line
+        uint64_t cap;
+        if (FASTQ) {
+            const unsigned long long fbh = st->first_blank_head;
+            const uint64_t leff = fbh != ~0ull && fbh < st->nlines ? fbh : st->nlines;
+            cap = leff / 4;
+        } else {
+            cap = final ? ch : (ch > 1 ? ch - 1 : 0);
+        }
+        st->nrec_cap = cap <= max_records ? cap : 0;       // (more than the tables hold: a capacity error, nothing is written)
+    }
 }
 
+// The scan proper, and what every head line contributes to the batch: its record's offset and name span (a head
+// line of rank r opens record r; FASTA: a non-blank line before the first head line is a format error).  Records
+// beyond `nrec_cap` -- the number of complete records, known before this pass from the head count or the line
+// count, and never more than the tables hold -- are not written.
 template <bool FASTQ>
 __global__ __launch_bounds__(PB) void k_line_scan(const uint32_t* __restrict__ line_len,
-                                                  const uint8_t* __restrict__ line_head, const ParseState* st,
+                                                  const uint8_t* __restrict__ line_head, ParseState* st,
                                                   const LineSum* __restrict__ part, uint64_t* __restrict__ line_dst,
-                                                  uint32_t* __restrict__ line_rank)
+                                                  uint32_t* __restrict__ line_rank, const uint64_t* __restrict__ line_start,
+                                                  uint64_t max_records, uint64_t* __restrict__ offsets,
+                                                  uint64_t* __restrict__ name_pos, uint32_t* __restrict__ name_len)
 {
     __shared__ uint64_t s_b[PB / 64];
     __shared__ uint32_t s_h[PB / 64];
@@ -514,10 +564,19 @@ __global__ __launch_bounds__(PB) void k_line_scan(const uint32_t* __restrict__ l
     __syncthreads();
     uint64_t rb = part[blockIdx.x].bytes + ib - b; uint32_t rh = part[blockIdx.x].heads + ih - h;
     for (uint32_t w = 0; w < wave; w++) { rb += s_b[w]; rh += s_h[w]; }
+    const uint64_t nrec_cap = st->nrec_cap;
     if (base + SCAN_ITEMS <= nlines) {                    // 16-byte stores
         uint64_t d[SCAN_ITEMS]; uint32_t r[SCAN_ITEMS];
 #pragma unroll
         for (int k = 0; k < SCAN_ITEMS; k++) { d[k] = rb; r[k] = rh; rb += v[k].bytes; rh += v[k].heads; }
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; k++) {
+            if (v[k].heads) {
+                if (r[k] < nrec_cap) { offsets[r[k]] = d[k]; name_pos[r[k]] = line_start[base + k] + 1; name_len[r[k]] = len[k] - 1; }
+            } else if (!FASTQ && r[k] == 0 && len[k] != 0) {
+                atomicMin(&st->err_line, (unsigned long long)(base + k));
+            }
+        }
 #pragma unroll
         for (int k = 0; k < SCAN_ITEMS; k += 2)
             *reinterpret_cast<uint4*>(line_dst + base + k) =
@@ -529,7 +588,14 @@ __global__ __launch_bounds__(PB) void k_line_scan(const uint32_t* __restrict__ l
     }
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; k++) {
-        if (base + k < nlines) { line_dst[base + k] = rb; line_rank[base + k] = rh; }
+        if (base + k < nlines) {
+            line_dst[base + k] = rb; line_rank[base + k] = rh;
+            if (v[k].heads) {
+                if (rh < nrec_cap) { offsets[rh] = rb; name_pos[rh] = line_start[base + k] + 1; name_len[rh] = len[k] - 1; }
+            } else if (!FASTQ && rh == 0 && len[k] != 0) {
+                atomicMin(&st->err_line, (unsigned long long)(base + k));
+            }
+        }
         rb += v[k].bytes; rh += v[k].heads;
     }
 }
@@ -549,7 +615,8 @@ __device__ __forceinline__ uint64_t start_of_line(uint64_t k, uint64_t nlines, u
 template <bool FASTQ>
 __global__ void k_parse_decide(ParseState* st, uint64_t n, int final, uint64_t max_lines,
                                const uint64_t* __restrict__ nlpos, const uint64_t* __restrict__ line_start,
-                               const uint64_t* __restrict__ line_dst, const uint32_t* __restrict__ line_rank)
+                               const uint64_t* __restrict__ line_dst, const uint32_t* __restrict__ line_rank,
+                               uint64_t max_records, uint64_t* __restrict__ offsets)
 {
     const uint64_t L = st->nlines, n_nl = st->n_nl;
     uint64_t nrec = 0, seq_bytes = 0, consumed = 0;
@@ -588,33 +655,7 @@ __global__ void k_parse_decide(ParseState* st, uint64_t n, int final, uint64_t m
         }
     }
     st->status = status; st->nrec = nrec; st->seq_bytes = seq_bytes; st->consumed = consumed;
-}
-
-// Per line: head lines write their record's offset and name span.  FASTA: a non-blank line
-// before the first head line is a format error.
-template <bool FASTQ>
-__global__ __launch_bounds__(PB) void k_parse_emit(ParseState* st, uint64_t max_records,
-                                                   const uint64_t* __restrict__ line_start,
-                                                   const uint32_t* __restrict__ line_len,
-                                                   const uint8_t* __restrict__ line_head,
-                                                   const uint64_t* __restrict__ line_dst,
-                                                   const uint32_t* __restrict__ line_rank,
-                                                   uint64_t* __restrict__ offsets, uint64_t* __restrict__ name_pos,
-                                                   uint32_t* __restrict__ name_len)
-{
-    const uint64_t nrec = st->nrec, nlines = st->nlines;
-    if (st->status != PARSE_OK || nrec > max_records) return;
-    if (blockIdx.x == 0 && threadIdx.x == 0) offsets[nrec] = st->seq_bytes;
-    for (uint64_t i = (uint64_t)blockIdx.x * PB + threadIdx.x; i < nlines; i += (uint64_t)gridDim.x * PB) {
-        const bool head = line_head[i] != 0;
-        const uint32_t rank = line_rank[i];
-        if (!FASTQ && !head && rank == 0 && line_len[i] != 0) atomicMin(&st->err_line, (unsigned long long)i);
-        if (head && rank < nrec) {
-            offsets[rank] = line_dst[i];
-            name_pos[rank] = line_start[i] + 1;
-            name_len[rank] = line_len[i] - 1;
-        }
-    }
+    if (status == PARSE_OK && nrec <= max_records) offsets[nrec] = seq_bytes;
 }
 
 __device__ __forceinline__ uint64_t shfl64(uint64_t v, uint32_t src_lane)
@@ -895,7 +936,7 @@ static inline uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a
 
 // Workspace layout for `max_lines` lines and `text_bytes` of text (all sections 256-byte aligned).
 struct ParseLayout {
-    uint64_t state, tile_count, tile_base, nlpos, line_start, line_len, line_head, line_dst, line_rank, part, end;
+    uint64_t state, tile_count, tile_base, tile_last, nl_tile, nlpos, line_start, line_len, line_head, line_dst, line_rank, part, end;
     ParseLayout(uint64_t text_bytes, uint64_t max_lines)
     {
         const uint64_t ntile = (text_bytes + TILE - 1) / TILE + 1;
@@ -903,7 +944,9 @@ struct ParseLayout {
         uint64_t o = 0;
         state = o; o = align_up(o + sizeof(ParseState), 256);
         tile_count = o; o = align_up(o + ntile * 4, 256);
-        tile_base = o; o = align_up(o + ntile * 8, 256);
+        tile_base = o; o = align_up(o + (ntile + 1) * 8, 256);
+        tile_last = o; o = align_up(o + ntile * 8, 256);
+        nl_tile = o; o = align_up(o + ntile * (uint64_t)TILE * 4, 256);      // address space: only the entries that exist are touched
         nlpos = o; o = align_up(o + max_lines * 8, 256);
         line_start = o; o = align_up(o + max_lines * 8, 256);
         line_len = o; o = align_up(o + max_lines * 4, 256);
@@ -929,6 +972,8 @@ static hipError_t launch_parse_t(const uint8_t* text, uint64_t n, int final, uin
     ParseState* st = reinterpret_cast<ParseState*>(ws + lay.state);
     uint32_t* tile_count = reinterpret_cast<uint32_t*>(ws + lay.tile_count);
     uint64_t* tile_base = reinterpret_cast<uint64_t*>(ws + lay.tile_base);
+    uint64_t* tile_last = reinterpret_cast<uint64_t*>(ws + lay.tile_last);
+    uint32_t* nl_tile = reinterpret_cast<uint32_t*>(ws + lay.nl_tile);
     uint64_t* nlpos = reinterpret_cast<uint64_t*>(ws + lay.nlpos);
     uint64_t* line_start = reinterpret_cast<uint64_t*>(ws + lay.line_start);
     uint32_t* line_len = reinterpret_cast<uint32_t*>(ws + lay.line_len);
@@ -947,17 +992,17 @@ static hipError_t launch_parse_t(const uint8_t* text, uint64_t n, int final, uin
     const uint64_t npart = (lines_cap + SCAN_TILE - 1) / SCAN_TILE ? (lines_cap + SCAN_TILE - 1) / SCAN_TILE : 1;
     const uint32_t gc = capped((lines_cap * 8 + PB - 1) / PB);
 
-    hipLaunchKernelGGL(k_nl_count, dim3(gt), dim3(PB), 0, s, text, n, tile_count);
+    hipLaunchKernelGGL(k_nl_index, dim3(gt), dim3(PB), 0, s, text, n, tile_count, tile_last, nl_tile);
     hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, tile_count, ntile, tile_base, &st->n_nl);
-    hipLaunchKernelGGL(k_nl_scatter, dim3(gt), dim3(PB), 0, s, text, n, tile_base, nlpos, max_lines);
     hipLaunchKernelGGL(k_parse_init, dim3(1), dim3(1), 0, s, st, n, final, text, max_lines);
-    hipLaunchKernelGGL((k_line_table<FASTQ>), dim3(gl < 2048 ? gl : 2048), dim3(PB), 0, s, text, n, nlpos, st, line_start, line_len, line_head);
+    hipLaunchKernelGGL((k_line_table<FASTQ>), dim3(gl < 2048 ? gl : 2048), dim3(PB), 0, s, text, n, ntile, nl_tile, tile_count, tile_base,
+                       tile_last, st, nlpos, line_start, line_len, line_head);
     hipLaunchKernelGGL((k_line_partials<FASTQ>), dim3((uint32_t)npart), dim3(PB), 0, s, line_len, line_head, st, part);
-    hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, s, part, npart, st);
-    hipLaunchKernelGGL((k_line_scan<FASTQ>), dim3((uint32_t)npart), dim3(PB), 0, s, line_len, line_head, st, part, line_dst, line_rank);
-    hipLaunchKernelGGL((k_parse_decide<FASTQ>), dim3(1), dim3(1), 0, s, st, n, final, max_lines, nlpos, line_start, line_dst, line_rank);
-    hipLaunchKernelGGL((k_parse_emit<FASTQ>), dim3(gl), dim3(PB), 0, s, st, max_records, line_start, line_len, line_head,
-                       line_dst, line_rank, offsets, name_pos, name_len);
+    hipLaunchKernelGGL((k_scan_partials<FASTQ>), dim3(1), dim3(1024), 0, s, part, npart, st, final, max_records);
+    hipLaunchKernelGGL((k_line_scan<FASTQ>), dim3((uint32_t)npart), dim3(PB), 0, s, line_len, line_head, st, part, line_dst, line_rank,
+                       line_start, max_records, offsets, name_pos, name_len);
+    hipLaunchKernelGGL((k_parse_decide<FASTQ>), dim3(1), dim3(1), 0, s, st, n, final, max_lines, nlpos, line_start, line_dst, line_rank,
+                       max_records, offsets);
     hipLaunchKernelGGL((k_parse_copy<FASTQ>), dim3(gc), dim3(PB), 0, s, st, max_records, seq_capacity, text, line_start,
                        line_len, line_head, line_dst, line_rank, seq, qual);
     hipLaunchKernelGGL((k_parse_copy_long<FASTQ>), dim3(1024), dim3(PB), 0, s, st, max_records, seq_capacity, text, n,
