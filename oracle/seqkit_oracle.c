@@ -596,6 +596,27 @@ int ora_cmd_seq(const ora_seq_opts *o, int nfiles, const char **files, FILE *out
 }
 
 /* ------------------------------------------------------------------ fx2tab */
+/* The numeric columns of fx2tab rows (fx2tab.go:127-143) for n records given by their base counts, without
+ * the records themselves: per record "\t<len>\t<GC>\t<GC-skew>\t<content of g>\n", with
+ * g = float64(ng)/float64(len), c = float64(nc)/float64(len) divided separately, GC = (g+c)*100,
+ * skew = (g-c)/(g+c)*100, content = g*100, each through ora_fmt_fixed(.., 2); a record of length 0 has g = c = 0
+ * (fx2tab.go: BaseContent of an empty sequence).  Returns the bytes written (out holds >= 64 * n). */
+size_t ora_tab_number_rows(const uint64_t *ng, const uint64_t *nc, const uint64_t *len, size_t n, char *out)
+{
+    char num[400];
+    size_t o = 0;
+    for (size_t i = 0; i < n; i++) {
+        const double g = len[i] ? (double)ng[i] / (double)len[i] : 0.0;
+        const double c = len[i] ? (double)nc[i] / (double)len[i] : 0.0;
+        o += (size_t)sprintf(out + o, "\t%llu", (unsigned long long)len[i]);
+        ora_fmt_fixed((g + c) * 100, 2, num); o += (size_t)sprintf(out + o, "\t%s", num);
+        ora_fmt_fixed((g - c) / (g + c) * 100, 2, num); o += (size_t)sprintf(out + o, "\t%s", num);
+        ora_fmt_fixed(g * 100, 2, num); o += (size_t)sprintf(out + o, "\t%s", num);
+        out[o++] = '\n';
+    }
+    return o;
+}
+
 static int cmp_u8(const void *a, const void *b) { return (int)*(const uint8_t *)a - (int)*(const uint8_t *)b; }
 
 /* seqkit/cmd/fx2tab.go:68-149. */

@@ -79,6 +79,8 @@ void ora_comma(int64_t v, char *buf);
 void ora_commaf(double v, char *buf);
 /* Go's fmt "%.<prec>f" incl. NaN/Inf spelling; buf >= 400 bytes */
 void ora_fmt_fixed(double v, int prec, char *buf);
+/* fx2tab.go:127-143 for records given by their counts: "\t<len>\t<GC>\t<GC-skew>\t<content>\n" per record */
+size_t ora_tab_number_rows(const uint64_t *ng, const uint64_t *nc, const uint64_t *len, size_t n, char *out);
 
 /* ---- the same per-record functions looped over a CSR batch (seq bytes back to back,
  * offs[nrec+1]); what the GPU entry points are compared with ---- */

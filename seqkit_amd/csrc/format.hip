@@ -612,14 +612,14 @@ __global__ __launch_bounds__(FB) void k_fmt_write_long(const FormatSeqArgs a, co
 // number of decimal digits of v, and v in decimal at buf[0 .. nd) (32-bit arithmetic whenever v fits)
 __device__ __forceinline__ uint32_t ndigits(uint64_t v)
 {
-    uint32_t n = 1;
     if (v >> 32) {
+        uint32_t n = 1;
         while (v >= 10) { v /= 10; n++; }
         return n;
     }
-    uint32_t x = (uint32_t)v;
-    while (x >= 10) { x /= 10; n++; }
-    return n;
+    const uint32_t x = (uint32_t)v;                       // comparisons, no loop whose length differs between lanes
+    return 1u + (x >= 10u) + (x >= 100u) + (x >= 1000u) + (x >= 10000u) + (x >= 100000u) + (x >= 1000000u) +
+           (x >= 10000000u) + (x >= 100000000u) + (x >= 1000000000u);
 }
 
 __device__ __forceinline__ void put_decimal(uint64_t v, uint32_t nd, uint8_t* buf)
@@ -669,9 +669,21 @@ __device__ __forceinline__ uint32_t fixed2_text(const Fixed2& f, uint8_t* buf)
     if (f.kind == 2) { if (PUT) { buf[0] = f.neg ? '-' : '+'; buf[1] = 'I'; buf[2] = 'n'; buf[3] = 'f'; } return 4; }
     uint32_t n = 0;
     if (f.neg) { if (PUT) buf[0] = '-'; n = 1; }
-    const uint32_t nd = ndigits(f.ip);
+    uint32_t nd;
+    if (f.ip < 1000) {                                    // percentages: three digits at most, no loops
+        const uint32_t ip = (uint32_t)f.ip, h = ip / 100, t = ip / 10 - 10 * h, u = ip - 10 * (ip / 10);
+        nd = 1u + (ip >= 10u) + (ip >= 100u);
+        if (PUT) {
+            uint8_t* o = buf + n;
+            if (ip >= 100u) *o++ = (uint8_t)('0' + h);
+            if (ip >= 10u) *o++ = (uint8_t)('0' + t);
+            *o = (uint8_t)('0' + u);
+        }
+    } else {
+        nd = ndigits(f.ip);
+        if (PUT) put_decimal(f.ip, nd, buf + n);
+    }
     if (PUT) {
-        put_decimal(f.ip, nd, buf + n);
         buf[n + nd] = '.';
         buf[n + nd + 1] = (uint8_t)('0' + f.fp / 10);
         buf[n + nd + 2] = (uint8_t)('0' + f.fp % 10);
