@@ -606,6 +606,10 @@ def main():
         seq, qual = keep
 
     if rank == 0:
+        # the kernel the library picked for this batch shape (its own selection, asked for, not assumed)
+        kname = C.create_string_buffer(128)
+        lib.check(lib.skh_kernel_for(ctx, seqkit_amd.capi.OP_REVCOMP, nrec, total, 1, kname, 128))
+        rev_kernel = kname.value.decode()
         ms = elapsed / args.steps * 1e3
         value = world * total * args.steps / elapsed / 1e9
         rev_bytes = 2.0 * total + 8.0 * (nrec + 1)          # one plane read + written, offsets read
@@ -621,10 +625,10 @@ def main():
                                    "(reverse-complement + quality reversal) then fx2tab -g -B AGCT counts, "
                                    "resident in HBM" % (nrec, L),
                        "records_per_gpu": nrec, "read_len": L, "parallelism": "records sharded, %d rank(s)" % world},
-            "roofline": {"bound": "hbm", "kernel": "skh::k_reverse_staged<true, false> (bases: reverse + complement, two planes)",
+            "roofline": {"bound": "hbm", "kernel": rev_kernel + " (bases: reverse + complement, two planes)",
                          "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": measured_traffic("skh::k_reverse_staged<true, false>")
+                         "traffic": measured_traffic(rev_kernel)
                          if (nrec, L) == (10_000_000, 150) else None,
                          "traffic_source": "committed rocprofv3 --pmc passes under profiles/ whose kernels.hip hash (%s) "
                                            "matches this tree; null otherwise" % kernels_sha16(),

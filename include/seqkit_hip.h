@@ -94,6 +94,18 @@ int skh_revcomp_dev(skh_ctx *ctx, const uint8_t *d_in, uint8_t *d_out,
                     const uint64_t *d_offsets, uint64_t nrec, uint64_t total_bytes,
                     const uint8_t *lut, int do_reverse, void *stream);
 
+/* Which kernel serves the records up to the long-record threshold for a batch of this shape on this context
+ * (the selection the entry points make from the number of records, the bytes and the context's settings): its
+ * name as the profiler shows it, e.g. "skh::k_reverse_flat<true>".  op: SKH_OP_REVCOMP (out of place) and
+ * SKH_OP_REVCOMP_INPLACE, with `variant` != 0 when a table is applied (complement); SKH_OP_COUNT, with
+ * `variant` = the number of classes.  For tools that label measurements; returns SKH_EINVAL for an unknown op
+ * or a buffer that is too small.  No counterpart in the reference. */
+#define SKH_OP_REVCOMP         1
+#define SKH_OP_REVCOMP_INPLACE 2
+#define SKH_OP_COUNT           3
+int skh_kernel_for(skh_ctx *ctx, int op, uint64_t nrec, uint64_t total_bytes, int variant,
+                   char *name, uint64_t name_bytes);
+
 /* FASTQ form of the above in one pass: bases are reversed (if do_reverse) and mapped
  * through lut, qualities are reversed (if do_reverse) and otherwise copied
  * (seq.go:188 reverses Seq and Qual together; seq.go:194 touches Seq only). */

@@ -41,6 +41,7 @@ class TabFormat(C.Structure):
 
 
 TAB_LENGTH, TAB_GC, TAB_GC_SKEW, TAB_CONTENT = 0, 1, 2, 3
+OP_REVCOMP, OP_REVCOMP_INPLACE, OP_COUNT = 1, 2, 3
 
 
 class Slice(C.Structure):
@@ -84,6 +85,7 @@ SYMBOLS = {
     "skh_count_dev": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_uint64, u8p, C.c_uint32, vp, vp]),
     "skh_stats_dev": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_uint64, u8p, vp, vp]),
     "skh_stats_static_dev": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_uint64, u8p, vp, vp]),
+    "skh_kernel_for": (C.c_int, [vp, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_char_p, C.c_uint64]),
     "skh_parse_workspace_size": (C.c_uint64, [C.c_uint64, C.c_uint64]),
     "skh_parse_dev": (C.c_int, [vp, vp, C.c_uint64, C.c_int, C.c_int, vp, vp, C.c_uint64, vp, vp, vp, C.c_uint64,
                                 vp, C.c_uint64, C.c_uint64, vp, vp]),

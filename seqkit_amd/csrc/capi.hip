@@ -382,6 +382,31 @@ int skh_revcomp_dev(skh_ctx* ctx, const uint8_t* d_in, uint8_t* d_out, const uin
     return revcomp_impl(ctx, d_in, d_out, nullptr, nullptr, d_offsets, nrec, total_bytes, lut, do_reverse, st);
 }
 
+int skh_kernel_for(skh_ctx* ctx, int op, uint64_t nrec, uint64_t total, int variant, char* name, uint64_t name_bytes)
+{
+    if (!ctx || !name) return fail(SKH_EINVAL, "ctx or name is NULL");
+    const skh::LaunchCfg cfg = cfg_for(ctx, nrec, total);
+    char buf[96];
+    const char* tf = variant ? "true" : "false";
+    if (op == SKH_OP_REVCOMP) {
+        if (cfg.span_u) snprintf(buf, sizeof buf, "skh::k_reverse_span<%s, %d>", tf, cfg.span_u);
+        else if (cfg.flat) snprintf(buf, sizeof buf, "skh::k_reverse_flat<%s>", tf);
+        else if (cfg.staged) snprintf(buf, sizeof buf, "skh::k_reverse_staged<%s, false>", tf);
+        else snprintf(buf, sizeof buf, "skh::k_reverse_short<%s, false>", tf);
+    } else if (op == SKH_OP_REVCOMP_INPLACE) {
+        if (cfg.flat_inplace) snprintf(buf, sizeof buf, "skh::k_reverse_flat_inplace<%s>", tf);
+        else if (cfg.staged) snprintf(buf, sizeof buf, "skh::k_reverse_staged<%s, true>", tf);
+        else snprintf(buf, sizeof buf, "skh::k_reverse_inplace_short<%s>", tf);
+    } else if (op == SKH_OP_COUNT) {
+        snprintf(buf, sizeof buf, "skh::k_count_short<%d, %d>", variant <= 4 ? 1 : 2, cfg.count_u == 4 || cfg.count_u == 5 ? cfg.count_u : 3);
+    } else {
+        return fail(SKH_EINVAL, "unknown op");
+    }
+    if (strlen(buf) + 1 > name_bytes) return fail(SKH_EINVAL, "name buffer too small");
+    memcpy(name, buf, strlen(buf) + 1);
+    return SKH_OK;
+}
+
 int skh_revcomp_fastq_dev(skh_ctx* ctx, const uint8_t* d_seq_in, uint8_t* d_seq_out,
                           const uint8_t* d_qual_in, uint8_t* d_qual_out, const uint64_t* d_offsets,
                           uint64_t nrec, uint64_t total_bytes, const uint8_t* lut, int do_reverse,

@@ -724,6 +724,13 @@ int skh_comm_init_rank(skh_ctx* ctx, const uint8_t*, int nranks, int rank, skh_c
 }
 void skh_comm_destroy(skh_comm* c) { delete c; }
 int skh_comm_local_ranks(const skh_comm* c) { return c ? (int)c->ctx.size() : 0; }
+int skh_kernel_for(skh_ctx* ctx, int op, uint64_t, uint64_t, int, char* name, uint64_t name_bytes)
+{
+    if (!ctx || !name || op < SKH_OP_REVCOMP || op > SKH_OP_COUNT || name_bytes < 9) return SKH_EINVAL;
+    memcpy(name, "cpu stub", 9);
+    return SKH_OK;
+}
+
 int skh_comm_rccl_version(int* runtime_version, int* header_version, int* shared_with_process)
 {
     if (runtime_version) *runtime_version = 0;
