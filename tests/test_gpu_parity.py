@@ -437,7 +437,8 @@ def test_round_trip_at_bench_size(lib, ctx):
     assert int(c1.sum()) == int((seq != ord("N")).sum())
 
 
-@pytest.mark.parametrize("shape", ["reads100", "trimmed30_151", "heavy_tail", "kilobases"])
+@pytest.mark.parametrize("shape", ["reads100", "trimmed30_151", "heavy_tail", "kilobases", "hairpin_like", "reads_and_contigs",
+                                   "reads_and_12kb"])
 def test_round_trip_at_scale_ragged(lib, ctx_default, shape):
     # Size-independent properties on batches of 0.2-0.5 Gbases whose lengths are not the bench's 150: reversing and
     # complementing twice is the identity (out of place and in place), the first pass equals the in-place pass, and
@@ -447,7 +448,13 @@ def test_round_trip_at_scale_ragged(lib, ctx_default, shape):
     rng = np.random.default_rng(17)
     lengths = {"reads100": np.full(3_000_000, 100), "trimmed30_151": rng.integers(30, 152, 3_000_000),
                "heavy_tail": np.clip(np.exp(rng.normal(np.log(120), 0.7, 2_000_000)), 1, 40000).astype(np.int64),
-               "kilobases": rng.integers(500, 2500, 300_000)}[shape].astype(np.int64)
+               "kilobases": rng.integers(500, 2500, 300_000),
+               # precursor-like lengths around 100 with a tail to 2354 (the flat kernel's overflow steps by lane groups)
+               "hairpin_like": np.clip(np.exp(rng.normal(np.log(100), 0.35, 3_000_000)), 39, 2354),
+               # reads with a few long contigs among them (the launch's list of long records), and with one record in
+               # ten of 12 kb (steps that overflow the stage served by whole wavefronts)
+               "reads_and_contigs": np.where(rng.random(1_500_000) < 1e-4, rng.integers(100_000, 3_000_000, 1_500_000), 150),
+               "reads_and_12kb": np.where(rng.random(600_000) < 0.1, 12000, 150)}[shape].astype(np.int64)
     offs_h = np.zeros(len(lengths) + 1, np.int64); np.cumsum(lengths, out=offs_h[1:])
     nrec, total = len(lengths), int(offs_h[-1])
     g = torch.Generator(device="cuda:0"); g.manual_seed(3)
