@@ -344,7 +344,10 @@ __global__ __launch_bounds__(PB) void k_line_table(const uint8_t* __restrict__ t
     // thread finds the tile of its line among the group's bases.  They leave as the dense table of 64-bit entries
     // the later passes look lines up in.  The unterminated last line, if any, is line n_nl.
     const uint64_t ngroup = (ntile + LT_TILES - 1) / LT_TILES;
-    for (uint64_t g = blockIdx.x; g <= ngroup; g += gridDim.x) {
+    // (from the last group down: the workgroups that run first then hold the highest line numbers, and the others
+    // find in st->last_nonblank a value they cannot raise -- see the atomics at the end)
+    for (uint64_t gr = blockIdx.x; gr <= ngroup; gr += gridDim.x) {
+        const uint64_t g = ngroup - gr;
         const uint64_t T0 = g * LT_TILES;
         __syncthreads();
         if (threadIdx.x <= LT_TILES) { const uint64_t t = T0 + threadIdx.x; s_base[threadIdx.x] = tile_base[t < ntile ? t : ntile]; }
@@ -357,42 +360,59 @@ __global__ __launch_bounds__(PB) void k_line_table(const uint8_t* __restrict__ t
         uint64_t i_lo = s_base[0], i_hi = s_base[LT_TILES];
         if (g == ngroup) { i_lo = n_nl; i_hi = nlines > n_nl ? n_nl + 1 : n_nl; }     // the line without a newline
         if (i_hi > nlines) i_hi = nlines;
-        for (uint64_t i = i_lo + threadIdx.x; i < i_hi; i += PB) {
-            uint64_t e_here = 0, e_before;
-            if (i < n_nl) {
-                uint32_t w = 0;
+        constexpr int LB = 4;                             // lines per thread whose entries are loaded before the first is used
+        for (uint64_t ib = i_lo + threadIdx.x; ib < i_hi; ib += (uint64_t)PB * LB) {
+            uint32_t ent_here[LB], ent_before[LB], w_of[LB], k_of[LB];
 #pragma unroll
-                for (uint32_t x = 1; x < LT_TILES; x++) w += s_base[x] <= i ? 1u : 0u;      // tile T0 + w holds newline i
-                const uint64_t t = T0 + w, t0 = t * TILE;
-                const uint32_t k = (uint32_t)(i - s_base[w]);
-                const uint32_t* ent = nl_tile + t * TILE;
-                e_here = nl_entry64(ent[k], t0);
-                e_before = k ? nl_entry64(ent[k - 1], t0) : s_before[w];
-                nlpos[i] = e_here;
-            } else {
-                e_before = s_before[0];                      // (T0 >= ntile here: every slot holds the text's last newline)
+            for (int j = 0; j < LB; j++) {
+                const uint64_t i = ib + (uint64_t)j * PB;
+                ent_here[j] = 0; ent_before[j] = 0; w_of[j] = 0; k_of[j] = 0;
+                if (i < i_hi && i < n_nl) {
+                    uint32_t w = 0;
+#pragma unroll
+                    for (uint32_t x = 1; x < LT_TILES; x++) w += s_base[x] <= i ? 1u : 0u;  // tile T0 + w holds newline i
+                    const uint32_t k = (uint32_t)(i - s_base[w]);
+                    const uint32_t* ent = nl_tile + (T0 + w) * TILE;
+                    ent_here[j] = ent[k];
+                    if (k) ent_before[j] = ent[k - 1];
+                    w_of[j] = w; k_of[j] = k;
+                }
             }
-            uint64_t ls; uint32_t len; uint8_t c;
-            line_span(text, n, e_before, e_here, n_nl, i, ls, len, c);
-            bool head, bad = false;
-            if (!FASTQ) {
-                head = c == '>';
-            } else {
-                const uint32_t role = (uint32_t)(i & 3);
-                head = role == 0;
-                if (role == 0) {
-                    if (len == 0) blank_head = i < blank_head ? i : blank_head;
-                    else bad = c != '@';
-                } else if (role == 2) {
-                    bad = c != '+';
-                }                                            // role 3 (equal lengths) is checked by k_line_partials
+#pragma unroll
+            for (int j = 0; j < LB; j++) {
+                const uint64_t i = ib + (uint64_t)j * PB;
+                if (i >= i_hi) break;
+                uint64_t e_here = 0, e_before;
+                if (i < n_nl) {
+                    const uint64_t t0 = (T0 + w_of[j]) * TILE;
+                    e_here = nl_entry64(ent_here[j], t0);
+                    e_before = k_of[j] ? nl_entry64(ent_before[j], t0) : s_before[w_of[j]];
+                    nlpos[i] = e_here;
+                } else {
+                    e_before = s_before[0];                  // (T0 >= ntile here: every slot holds the text's last newline)
+                }
+                uint64_t ls; uint32_t len; uint8_t c;
+                line_span(text, n, e_before, e_here, n_nl, i, ls, len, c);
+                bool head, bad = false;
+                if (!FASTQ) {
+                    head = c == '>';
+                } else {
+                    const uint32_t role = (uint32_t)(i & 3);
+                    head = role == 0;
+                    if (role == 0) {
+                        if (len == 0) blank_head = i < blank_head ? i : blank_head;
+                        else bad = c != '@';
+                    } else if (role == 2) {
+                        bad = c != '+';
+                    }                                        // role 3 (equal lengths) is checked by k_line_partials
+                }
+                if (len) { last = i > last ? i : last; any = true; }
+                if (len > LONG_LINE) atomicAdd(&st->n_long, 1u);
+                if (bad && i < err) err = i;
+                line_start[i] = ls;
+                line_len[i] = len;
+                line_head[i] = head ? 1 : 0;
             }
-            if (len) { last = i > last ? i : last; any = true; }
-            if (len > LONG_LINE) atomicAdd(&st->n_long, 1u);
-            if (bad && i < err) err = i;
-            line_start[i] = ls;
-            line_len[i] = len;
-            line_head[i] = head ? 1 : 0;
         }
     }
     for (int d = 1; d < 64; d <<= 1) {
@@ -420,7 +440,16 @@ __global__ __launch_bounds__(PB) void k_line_table(const uint8_t* __restrict__ t
         }
         if (err != ~0ull) atomicMin(&st->err_line, err);
         if (blank_head != ~0ull) atomicMin(&st->first_blank_head, blank_head);
-        if (a) { atomicMax(&st->last_nonblank, last); st->any_nonblank = 1; }
+        // Same-address atomics serialise in L2 at some 15 ns each: 2,048 workgroups of them were half of this kernel.
+        // The maximum only grows, so a workgroup whose value is not above what it reads leaves it alone (a stale read
+        // costs an atomic, never a result; the reads go past the die's L2, which would keep its first answer).
+        if (a) {
+            if (last > __hip_atomic_load(&st->last_nonblank, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ||
+                !__hip_atomic_load(&st->any_nonblank, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                atomicMax(&st->last_nonblank, last);
+                st->any_nonblank = 1;
+            }
+        }
     }
 }
 
