@@ -262,6 +262,15 @@ int skh_subseq_dev(skh_ctx *ctx, const uint8_t *d_seq, const uint8_t *d_qual, co
  * skh_parse_workspace_size(text_bytes, max_lines) bytes. */
 #define SKH_FASTA 1
 #define SKH_FASTQ 2
+/* FASTQ as the reference's reader accepts it (README.md:88, doc/docs/usage.md:357-359): sequence and quality of a
+ * record may be wrapped over several lines -- sequence lines up to the first line that starts with '+', quality
+ * lines until they hold as many bytes as the sequence -- and blank lines may stand between records.  Four-line
+ * records are a special case, but SKH_FASTQ parses them several times faster; result.wrapped tells whether the
+ * block needed this format.  Which '@' lines start records is found by following, from the first line, the line
+ * each record would end at (pointer doubling over the line table).  Text that is not such FASTQ -- and a record cut
+ * short by the end of the file -- is SKH_PARSE_EFORMAT with error_line = -1: this format does not name the line.
+ * The workspace is skh_parse_wrapped_workspace_size(text_bytes, max_lines, max_records) bytes. */
+#define SKH_FASTQ_WRAPPED 3
 #define SKH_PARSE_OK        0
 #define SKH_PARSE_EFORMAT   1
 #define SKH_PARSE_ECAPACITY 2
@@ -272,9 +281,11 @@ typedef struct skh_parse_result {
     uint64_t lines;       /* text lines looked at                           */
     int64_t  error_line;  /* first offending line, or -1                    */
     uint32_t status;      /* SKH_PARSE_*                                    */
-    uint32_t reserved;
+    uint32_t wrapped;     /* SKH_FASTQ_WRAPPED: 1 = some record was not in the four-line form, or blank lines
+                           * stood between records; 0 otherwise and for the other formats */
 } skh_parse_result;
 uint64_t skh_parse_workspace_size(uint64_t text_bytes, uint64_t max_lines);
+uint64_t skh_parse_wrapped_workspace_size(uint64_t text_bytes, uint64_t max_lines, uint64_t max_records);
 int skh_parse_dev(skh_ctx *ctx, const uint8_t *d_text, uint64_t text_bytes, int format, int final,
                   uint8_t *d_seq, uint8_t *d_qual, uint64_t seq_capacity, uint64_t *d_offsets,
                   uint64_t *d_name_pos, uint32_t *d_name_len, uint64_t max_records,

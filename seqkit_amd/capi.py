@@ -22,7 +22,7 @@ class StatsPartial(C.Structure):
 
 class ParseResult(C.Structure):
     _fields_ = [("nrec", C.c_uint64), ("seq_bytes", C.c_uint64), ("consumed", C.c_uint64), ("lines", C.c_uint64),
-                ("error_line", C.c_int64), ("status", C.c_uint32), ("reserved", C.c_uint32)]
+                ("error_line", C.c_int64), ("status", C.c_uint32), ("wrapped", C.c_uint32)]
 
 
 class SeqFormat(C.Structure):
@@ -67,7 +67,7 @@ class FormatResult(C.Structure):
     _fields_ = [("out_bytes", C.c_uint64), ("status", C.c_uint32), ("reserved", C.c_uint32)]
 
 
-FASTA, FASTQ = 1, 2
+FASTA, FASTQ, FASTQ_WRAPPED = 1, 2, 3
 PARSE_OK, PARSE_EFORMAT, PARSE_ECAPACITY = 0, 1, 2
 
 SYMBOLS = {
@@ -87,6 +87,7 @@ SYMBOLS = {
     "skh_stats_static_dev": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_uint64, u8p, vp, vp]),
     "skh_kernel_for": (C.c_int, [vp, C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.c_char_p, C.c_uint64]),
     "skh_parse_workspace_size": (C.c_uint64, [C.c_uint64, C.c_uint64]),
+    "skh_parse_wrapped_workspace_size": (C.c_uint64, [C.c_uint64, C.c_uint64, C.c_uint64]),
     "skh_parse_dev": (C.c_int, [vp, vp, C.c_uint64, C.c_int, C.c_int, vp, vp, C.c_uint64, vp, vp, vp, C.c_uint64,
                                 vp, C.c_uint64, C.c_uint64, vp, vp]),
     "skh_format_workspace_size": (C.c_uint64, [C.c_uint64]),

@@ -621,6 +621,11 @@ uint64_t skh_parse_workspace_size(uint64_t text_bytes, uint64_t max_lines)
     return skh::parse_workspace_size(text_bytes, max_lines ? max_lines : 1);
 }
 
+uint64_t skh_parse_wrapped_workspace_size(uint64_t text_bytes, uint64_t max_lines, uint64_t max_records)
+{
+    return skh::parse_wrapped_workspace_size(text_bytes, max_lines ? max_lines : 1, max_records);
+}
+
 int skh_parse_dev(skh_ctx* ctx, const uint8_t* d_text, uint64_t text_bytes, int format, int final,
                   uint8_t* d_seq, uint8_t* d_qual, uint64_t seq_capacity, uint64_t* d_offsets,
                   uint64_t* d_name_pos, uint32_t* d_name_len, uint64_t max_records, void* d_workspace,
@@ -628,13 +633,25 @@ int skh_parse_dev(skh_ctx* ctx, const uint8_t* d_text, uint64_t text_bytes, int 
 {
     static_assert(sizeof(skh_parse_result) == sizeof(skh::ParseResult), "layout");
     if (!ctx) return fail(SKH_EINVAL, "ctx is NULL");
-    if (format != SKH_FASTA && format != SKH_FASTQ) return fail(SKH_EINVAL, "format must be SKH_FASTA or SKH_FASTQ");
+    if (format != SKH_FASTA && format != SKH_FASTQ && format != SKH_FASTQ_WRAPPED)
+        return fail(SKH_EINVAL, "format must be SKH_FASTA, SKH_FASTQ or SKH_FASTQ_WRAPPED");
     if (!d_offsets || !d_name_pos || !d_name_len || !d_workspace || !d_result) return fail(SKH_EINVAL, "NULL argument");
     if (text_bytes != 0 && (!d_text || !d_seq)) return fail(SKH_EINVAL, "NULL text or sequence buffer");
-    if (format == SKH_FASTQ && text_bytes != 0 && !d_qual) return fail(SKH_EINVAL, "FASTQ needs a quality buffer");
+    if (format != SKH_FASTA && text_bytes != 0 && !d_qual) return fail(SKH_EINVAL, "FASTQ needs a quality buffer");
     if (reinterpret_cast<uintptr_t>(d_text) & 15) return fail(SKH_EINVAL, "text buffer is not 16-byte aligned");
     if (reinterpret_cast<uintptr_t>(d_workspace) & 255) return fail(SKH_EINVAL, "workspace is not 256-byte aligned");
     if (max_lines == 0) return fail(SKH_EINVAL, "max_lines is 0");
+    if (format == SKH_FASTQ_WRAPPED) {
+        if (max_lines >= (1ull << 32) - 4) return fail(SKH_EINVAL, "SKH_FASTQ_WRAPPED: at most 2^32 - 5 lines per block");
+        if (workspace_bytes < skh::parse_wrapped_workspace_size(text_bytes, max_lines, max_records))
+            return fail(SKH_ECAPACITY, "workspace smaller than skh_parse_wrapped_workspace_size(text_bytes, max_lines, max_records)");
+        HIP_TRY(hipSetDevice(ctx->device));
+        hipStream_t wst = stream ? (hipStream_t)stream : ctx->stream;
+        HIP_TRY(skh::launch_parse_wrapped(d_text, text_bytes, final != 0, d_seq, d_qual, seq_capacity, d_offsets, d_name_pos,
+                                          d_name_len, max_records, d_workspace, max_lines,
+                                          reinterpret_cast<skh::ParseResult*>(d_result), wst));
+        return SKH_OK;
+    }
     if (workspace_bytes < skh::parse_workspace_size(text_bytes, max_lines))
         return fail(SKH_ECAPACITY, "workspace smaller than skh_parse_workspace_size(text_bytes, max_lines)");
     HIP_TRY(hipSetDevice(ctx->device));
@@ -975,6 +992,8 @@ struct skh_text {
     uint64_t *d_offs = nullptr, *d_npos = nullptr;
     uint32_t* d_nlen = nullptr;
     void *d_ws = nullptr, *d_fws = nullptr;
+    void* d_wws = nullptr;                  // workspace of SKH_FASTQ_WRAPPED, made when first asked for
+    uint64_t wws_bytes = 0;
     uint64_t ws_bytes = 0, fws_bytes = 0, fws_records = 0;
     uint8_t *d_out = nullptr, *h_out = nullptr;
     uint64_t out_cap = 0;
@@ -1019,7 +1038,9 @@ namespace {
 void text_free_lines(skh_text* t)
 {
     (void)hipFree(t->d_offs); (void)hipFree(t->d_npos); (void)hipFree(t->d_nlen); (void)hipFree(t->d_ws); (void)hipFree(t->d_fws);
-    t->d_offs = t->d_npos = nullptr; t->d_nlen = nullptr; t->d_ws = t->d_fws = nullptr;
+    (void)hipFree(t->d_wws);
+    t->d_offs = t->d_npos = nullptr; t->d_nlen = nullptr; t->d_ws = t->d_fws = t->d_wws = nullptr;
+    t->wws_bytes = 0;
 }
 
 hipError_t text_alloc_lines(skh_text* t, uint64_t max_lines)
@@ -1133,8 +1154,18 @@ int skh_text_parse_at(skh_ctx* ctx, skh_text* t, uint64_t text_offset, uint64_t 
     t->up_bytes = 0;
     t->text_off = text_offset;
     for (;;) {
+        void* ws = t->d_ws;
+        uint64_t ws_bytes = t->ws_bytes;
+        if (format == SKH_FASTQ_WRAPPED) {
+            if (!t->d_wws) {
+                t->wws_bytes = skh::parse_wrapped_workspace_size(t->cap, t->max_lines, t->max_lines);
+                hipError_t e = hipMalloc(&t->d_wws, t->wws_bytes);
+                if (e != hipSuccess) { t->d_wws = nullptr; return hip_fail(e, "allocating the workspace of the wrapped-FASTQ parser"); }
+            }
+            ws = t->d_wws; ws_bytes = t->wws_bytes;
+        }
         int rc = skh_parse_dev(ctx, t->d_text, text_bytes, format, final, t->d_seq, t->d_qual, t->cap, t->d_offs,
-                               t->d_npos, t->d_nlen, t->max_lines, t->d_ws, t->ws_bytes, t->max_lines,
+                               t->d_npos, t->d_nlen, t->max_lines, ws, ws_bytes, t->max_lines,
                                static_cast<skh_parse_result*>(t->d_res), t->stream);
         if (rc) return rc;
         HIP_TRY(hipMemcpyAsync(t->h_res, t->d_res, sizeof(skh_parse_result), hipMemcpyDeviceToHost, t->stream));
@@ -1146,7 +1177,7 @@ int skh_text_parse_at(skh_ctx* ctx, skh_text* t, uint64_t text_offset, uint64_t 
         hipError_t e = text_alloc_lines(t, t->max_lines * 4);
         if (e != hipSuccess) return hip_fail(e, "growing the line tables");
     }
-    t->fastq = format == SKH_FASTQ;
+    t->fastq = format != SKH_FASTA;
     t->nrec = out->status == SKH_PARSE_OK ? out->nrec : 0;
     t->seq_bytes = out->status == SKH_PARSE_OK ? out->seq_bytes : 0;
     t->text_bytes = text_bytes;

@@ -127,6 +127,13 @@ struct ParseResult {          // mirrors skh_parse_result of the C ABI
 };
 
 uint64_t parse_workspace_size(uint64_t text_bytes, uint64_t max_lines);
+// FASTQ with records wrapped over several lines (and four-line records among them): the same outputs, by a pass
+// sequence of its own; workspace = parse_wrapped_workspace_size (it contains the parser's own).  ParseResult.pad
+// is 1 when some record was not in the four-line form.
+uint64_t parse_wrapped_workspace_size(uint64_t text_bytes, uint64_t max_lines, uint64_t max_records);
+hipError_t launch_parse_wrapped(const uint8_t* text, uint64_t n, int final, uint8_t* seq, uint8_t* qual, uint64_t seq_capacity,
+                                uint64_t* offsets, uint64_t* name_pos, uint32_t* name_len, uint64_t max_records, void* workspace,
+                                uint64_t max_lines, ParseResult* res, hipStream_t s);
 hipError_t launch_parse(int fastq, const uint8_t* text, uint64_t n, int final, uint8_t* seq, uint8_t* qual,
                         uint64_t seq_capacity, uint64_t* offsets, uint64_t* name_pos, uint32_t* name_len,
                         uint64_t max_records, void* workspace, uint64_t max_lines, ParseResult* res, hipStream_t s);

@@ -332,7 +332,7 @@ __global__ __launch_bounds__(PB) void k_line_table(const uint8_t* __restrict__ t
                                                    const uint64_t* __restrict__ tile_base, const uint64_t* __restrict__ tile_last,
                                                    ParseState* st, uint64_t* __restrict__ nlpos,
                                                    uint64_t* __restrict__ line_start, uint32_t* __restrict__ line_len,
-                                                   uint8_t* __restrict__ line_head)
+                                                   uint8_t* __restrict__ line_head, int raw_first)
 {
     __shared__ uint64_t s_base[LT_TILES + 1], s_before[LT_TILES];
     const uint64_t nlines = st->nlines, n_nl = st->n_nl;
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(PB) void k_line_table(const uint8_t* __restrict__ t
                 if (bad && i < err) err = i;
                 line_start[i] = ls;
                 line_len[i] = len;
-                line_head[i] = head ? 1 : 0;
+                line_head[i] = raw_first ? c : (head ? 1 : 0);     // (raw_first: the line's first byte, for the wrapped-FASTQ passes)
             }
         }
     }
@@ -981,6 +981,205 @@ __global__ void k_parse_finish(const ParseState* st, uint64_t max_records, uint6
     *res = r;
 }
 
+
+// ---- FASTQ whose records are wrapped over several lines -----------------------------------------------------
+//
+// The reader the reference uses accepts FASTQ records with sequence and quality on several lines (README.md:88,
+// doc/docs/usage.md:357-359 of the reference): a record is a line that starts with '@', sequence lines up to the
+// first line that starts with '+', and quality lines until they hold as many bytes as the sequence; blank lines
+// may stand between records.  '@' and '+' may start a quality line, so which lines start records depends on every
+// record before -- but where a record WOULD end if it started at a given '@' line depends on that line alone: the
+// next '+' line, the bytes between, and the first line at which the bytes after the '+' line reach that number
+// (prefix sums of the line lengths, a binary search).  Every '@' line thus gets the line its successor would start
+// at, and the records of the text are the chain of successors from the first non-blank line: marked by pointer
+// doubling (a marked line marks its successor, successors are squared; log2(lines) rounds).  Anything else --
+// a chain that reaches a line that is not an '@' line, quality bytes that overshoot, an incomplete record at the
+// end of a file -- is reported as a format error without a line number: the caller's serial scan names the line.
+// All passes are element-wise over the line table or sums over it; nothing here is tuned (such files are rare,
+// and the serial rewrite they replace runs at 1 GB/s).
+struct WrapState { uint32_t status, wrapped; uint64_t consumed, lines, nrec; };
+constexpr uint32_t WQ_B = 256;
+
+// tmp[i] for the sums over lines: kind 0 = length, 1 = is a '+' line, 2 = is not blank (zero from line L on)
+__global__ __launch_bounds__(WQ_B) void k_wq_flags(const ParseState* st, const uint32_t* __restrict__ line_len,
+                                                   const uint8_t* __restrict__ line_first, int kind, uint64_t cap,
+                                                   uint64_t* __restrict__ tmp)
+{
+    const uint64_t L = st->nlines;
+    for (uint64_t i = (uint64_t)blockIdx.x * WQ_B + threadIdx.x; i < cap; i += (uint64_t)gridDim.x * WQ_B) {
+        uint64_t v = 0;
+        if (i < L) {
+            const uint32_t len = line_len[i];
+            v = kind == 0 ? len : (kind == 1 ? (len && line_first[i] == '+') : (len != 0));
+        }
+        tmp[i] = v;
+    }
+}
+
+// the c-th '+' line and the c-th non-blank line (entry number-of-them = L): first such line at or after i is
+// idx[count before i]
+__global__ __launch_bounds__(WQ_B) void k_wq_index(const ParseState* st, const uint32_t* __restrict__ line_len,
+                                                   const uint8_t* __restrict__ line_first, const uint64_t* __restrict__ cPlus,
+                                                   const uint64_t* __restrict__ cNb, uint64_t cap,
+                                                   uint32_t* __restrict__ plus_idx, uint32_t* __restrict__ nb_idx)
+{
+    const uint64_t L = st->nlines;
+    for (uint64_t i = (uint64_t)blockIdx.x * WQ_B + threadIdx.x; i <= L && i < cap; i += (uint64_t)gridDim.x * WQ_B) {
+        if (i == L) { plus_idx[cPlus[L]] = (uint32_t)L; nb_idx[cNb[L]] = (uint32_t)L; continue; }
+        const uint32_t len = line_len[i];
+        if (len) {
+            nb_idx[cNb[i]] = (uint32_t)i;
+            if (line_first[i] == '+') plus_idx[cPlus[i]] = (uint32_t)i;
+        }
+    }
+}
+
+// The record that would start at line i: its '+' line and its last line; false: there is none (*why: L + 1 =
+// the text ends before the record does, L + 2 = not a record).
+__device__ __forceinline__ bool wq_record(uint64_t i, uint64_t L, int final, const uint32_t* __restrict__ line_len,
+                                          const uint8_t* __restrict__ line_first, const uint64_t* __restrict__ cP,
+                                          const uint64_t* __restrict__ cPlus, const uint32_t* __restrict__ plus_idx,
+                                          uint64_t& plus, uint64_t& last, uint32_t& why)
+{
+    const uint32_t cut = (uint32_t)(final ? L + 2 : L + 1);
+    if (line_len[i] == 0 || line_first[i] != '@') { why = (uint32_t)(L + 2); return false; }
+    const uint64_t j = plus_idx[cPlus[i + 1]];
+    if (j >= L) { why = cut; return false; }
+    const uint64_t S = cP[j] - cP[i + 1];
+    plus = j; last = j;
+    if (S == 0) return true;
+    const uint64_t q0 = cP[j + 1];
+    if (cP[L] - q0 < S) { why = cut; return false; }
+    uint64_t lo = j + 1, hi = L - 1;                      // smallest k with cP[k + 1] - q0 >= S
+    while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (cP[mid + 1] - q0 >= S) hi = mid; else lo = mid + 1; }
+    if (cP[lo + 1] - q0 != S) { why = (uint32_t)(L + 2); return false; }       // more quality than sequence
+    last = lo;
+    return true;
+}
+
+// successor of every line; three lines behind the text stand for "the end", "cut" and "not a record"
+__global__ __launch_bounds__(WQ_B) void k_wq_next(const ParseState* st, int final, const uint32_t* __restrict__ line_len,
+                                                  const uint8_t* __restrict__ line_first, const uint64_t* __restrict__ cP,
+                                                  const uint64_t* __restrict__ cPlus, const uint64_t* __restrict__ cNb,
+                                                  const uint32_t* __restrict__ plus_idx, const uint32_t* __restrict__ nb_idx,
+                                                  uint64_t cap, uint32_t* __restrict__ nxt0, uint32_t* __restrict__ nxt,
+                                                  uint8_t* __restrict__ mark)
+{
+    const uint64_t L = st->nlines;
+    for (uint64_t i = (uint64_t)blockIdx.x * WQ_B + threadIdx.x; i < L + 3 && i < cap; i += (uint64_t)gridDim.x * WQ_B) {
+        uint32_t to = (uint32_t)i;                        // (the three lines behind the text lead to themselves)
+        if (i < L) {
+            uint64_t plus, last; uint32_t why = 0;
+            if (wq_record(i, L, final, line_len, line_first, cP, cPlus, plus_idx, plus, last, why)) to = nb_idx[cNb[last + 1]];
+            else to = why;
+        }
+        nxt0[i] = to; nxt[i] = to;
+        mark[i] = i == nb_idx[0] ? 1 : 0;                 // the first line that is not blank (L: there is none)
+    }
+}
+
+__global__ __launch_bounds__(WQ_B) void k_wq_jump(const ParseState* st, uint64_t cap, const uint32_t* __restrict__ a,
+                                                  uint32_t* __restrict__ b, uint8_t* __restrict__ mark)
+{
+    const uint64_t L = st->nlines;
+    for (uint64_t i = (uint64_t)blockIdx.x * WQ_B + threadIdx.x; i < L + 3 && i < cap; i += (uint64_t)gridDim.x * WQ_B) {
+        const uint32_t to = a[i];
+        if (mark[i]) mark[to] = 1;
+        b[i] = a[to];
+    }
+}
+
+// the marked lines whose record is complete start the records of the block; where the chain ends
+__global__ __launch_bounds__(WQ_B) void k_wq_emit(const ParseState* st, uint64_t n, int final, const uint64_t* __restrict__ nlpos,
+                                                  const uint64_t* __restrict__ line_start, const uint32_t* __restrict__ nxt0,
+                                                  const uint8_t* __restrict__ mark, uint64_t cap, uint64_t* __restrict__ tmp,
+                                                  WrapState* w)
+{
+    const uint64_t L = st->nlines;
+    for (uint64_t i = (uint64_t)blockIdx.x * WQ_B + threadIdx.x; i < cap; i += (uint64_t)gridDim.x * WQ_B) {
+        uint64_t e = 0;
+        if (i < L && mark[i]) {
+            if (nxt0[i] <= L) e = 1;
+            else if (nxt0[i] == L + 1) { w->consumed = line_start[i]; w->lines = i; }
+        }
+        tmp[i] = e;
+        if (i == L) {
+            if (mark[L + 2]) w->status = PARSE_EFORMAT;
+            if (mark[L]) {
+                w->lines = L;
+                w->consumed = final ? n : (L ? (nlpos[L - 1] & NL_POS) + 1 : 0);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(WQ_B) void k_wq_records(const ParseState* st, int final, const uint32_t* __restrict__ line_len,
+                                                     const uint8_t* __restrict__ line_first, const uint64_t* __restrict__ line_start,
+                                                     const uint64_t* __restrict__ cP, const uint64_t* __restrict__ cPlus,
+                                                     const uint64_t* __restrict__ cNb, const uint32_t* __restrict__ plus_idx,
+                                                     const uint32_t* __restrict__ nb_idx, const uint64_t* __restrict__ cRid,
+                                                     const uint64_t* __restrict__ is_start, uint64_t cap, uint64_t max_records,
+                                                     uint32_t* __restrict__ rec_start, uint32_t* __restrict__ rec_plus,
+                                                     uint32_t* __restrict__ rec_last, uint64_t* __restrict__ rec_S,
+                                                     uint64_t* __restrict__ name_pos, uint32_t* __restrict__ name_len, WrapState* w)
+{
+    const uint64_t L = st->nlines;
+    for (uint64_t i = (uint64_t)blockIdx.x * WQ_B + threadIdx.x; i < L && i < cap; i += (uint64_t)gridDim.x * WQ_B) {
+        if (!is_start[i]) continue;
+        const uint64_t r = cRid[i];
+        if (r >= max_records) continue;
+        uint64_t plus = 0, last = 0; uint32_t why;
+        wq_record(i, L, final, line_len, line_first, cP, cPlus, plus_idx, plus, last, why);
+        rec_start[r] = (uint32_t)i; rec_plus[r] = (uint32_t)plus; rec_last[r] = (uint32_t)last;
+        rec_S[r] = cP[plus] - cP[i + 1];
+        name_pos[r] = line_start[i] + 1; name_len[r] = line_len[i] - 1;
+        // anything but '@', one sequence line, '+', one quality line, the next record: the caller may want to know
+        if (plus != i + 2 || last != plus + 1 || nb_idx[cNb[last + 1]] != last + 1 || (r == 0 && i != 0)) w->wrapped = 1;
+    }
+}
+
+__global__ void k_wq_check(const ParseState* st, uint64_t max_lines, const uint64_t* __restrict__ nrec_total,
+                           const uint64_t* __restrict__ offsets, uint64_t max_records, uint64_t seq_capacity, WrapState* w)
+{
+    const uint64_t nrec = *nrec_total;
+    w->nrec = nrec;
+    if (st->n_nl + 1 > max_lines) w->status = PARSE_ECAPACITY;         // the line tables were too small for this text
+    if (w->status == PARSE_OK && (nrec > max_records || offsets[nrec] > seq_capacity)) w->status = PARSE_ECAPACITY;
+}
+
+// every sequence and quality line to its place: 8 lanes per line
+__global__ __launch_bounds__(WQ_B) void k_wq_copy(const ParseState* st, const WrapState* w, const uint8_t* __restrict__ text,
+                                                  const uint64_t* __restrict__ line_start, const uint32_t* __restrict__ line_len,
+                                                  const uint64_t* __restrict__ cP, const uint64_t* __restrict__ cRid,
+                                                  const uint32_t* __restrict__ rec_start, const uint32_t* __restrict__ rec_plus,
+                                                  const uint32_t* __restrict__ rec_last, const uint64_t* __restrict__ offsets,
+                                                  uint64_t cap, uint8_t* __restrict__ seq, uint8_t* __restrict__ qual)
+{
+    if (w->status != PARSE_OK) return;
+    const uint64_t L = st->nlines;
+    const uint32_t j = threadIdx.x & 7;
+    for (uint64_t i = ((uint64_t)blockIdx.x * WQ_B + threadIdx.x) >> 3; i < L && i < cap; i += ((uint64_t)gridDim.x * WQ_B) >> 3) {
+        const uint64_t before = cRid[i + 1];              // records that start at or before line i
+        const uint32_t len = line_len[i];
+        if (before == 0 || len == 0) continue;
+        const uint64_t r = before - 1;
+        const uint64_t start = rec_start[r], plus = rec_plus[r], last = rec_last[r];
+        if (i == start || i == plus || i > last) continue;
+        const bool is_q = i > plus;
+        const uint64_t dst = offsets[r] + (cP[i] - cP[(is_q ? plus : start) + 1]);
+        copy_line<8>((is_q ? qual : seq) + dst, text + line_start[i], len, j);
+    }
+}
+
+__global__ void k_wq_finish(const WrapState* w, const uint64_t* __restrict__ offsets, ParseResult* __restrict__ res)
+{
+    ParseResult r;
+    r.status = w->status; r.error_line = -1; r.pad = w->wrapped;
+    r.nrec = 0; r.seq_bytes = 0; r.consumed = 0; r.lines = w->lines;
+    if (r.status == PARSE_OK) { r.nrec = w->nrec; r.seq_bytes = offsets[w->nrec]; r.consumed = w->consumed; }
+    *res = r;
+}
+
 }  // namespace
 
 // ---- launcher ------------------------------------------------------------------------------
@@ -1049,7 +1248,7 @@ static hipError_t launch_parse_t(const uint8_t* text, uint64_t n, int final, uin
     hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, tile_count, ntile, tile_base, &st->n_nl);
     hipLaunchKernelGGL(k_parse_init, dim3(1), dim3(1), 0, s, st, n, final, text, max_lines);
     hipLaunchKernelGGL((k_line_table<FASTQ>), dim3(gl < 2048 ? gl : 2048), dim3(PB), 0, s, text, n, ntile, nl_tile, tile_count, tile_base,
-                       tile_last, st, nlpos, line_start, line_len, line_head);
+                       tile_last, st, nlpos, line_start, line_len, line_head, 0);
     hipLaunchKernelGGL((k_line_partials<FASTQ>), dim3((uint32_t)npart), dim3(PB), 0, s, line_len, line_head, st, part);
     hipLaunchKernelGGL((k_scan_partials<FASTQ>), dim3(1), dim3(1024), 0, s, part, npart, st, final, max_records);
     hipLaunchKernelGGL((k_line_scan<FASTQ>), dim3((uint32_t)npart), dim3(PB), 0, s, line_len, line_head, st, part, line_dst, line_rank,
@@ -1073,6 +1272,117 @@ hipError_t launch_parse(int fastq, const uint8_t* text, uint64_t n, int final, u
                                         max_records, ws, max_lines, res, s)
                  : launch_parse_t<false>(text, n, final, seq, qual, seq_capacity, offsets, name_pos, name_len,
                                          max_records, ws, max_lines, res, s);
+}
+
+// Workspace of the wrapped-FASTQ passes, behind the parser's own (all sections 256-byte aligned).
+struct WrapLayout {
+    uint64_t state, total, tmp, cP, cPlus, cNb, cRid, part, plus_idx, nb_idx, nxt0, nxtA, nxtB, mark, rec_start, rec_plus, rec_last, rec_S, end;
+    WrapLayout(uint64_t base, uint64_t max_lines, uint64_t max_records)
+    {
+        const uint64_t Lc = max_lines + 4, Rc = max_records + 2;
+        uint64_t o = align_up(base, 256);
+        state = o; o = align_up(o + sizeof(WrapState), 256);
+        total = o; o = align_up(o + 64, 256);
+        tmp = o; o = align_up(o + Lc * 8, 256);
+        cP = o; o = align_up(o + Lc * 8, 256);
+        cPlus = o; o = align_up(o + Lc * 8, 256);
+        cNb = o; o = align_up(o + Lc * 8, 256);
+        cRid = o; o = align_up(o + Lc * 8, 256);
+        part = o; o = align_up(o + scan64_partials(Lc > Rc ? Lc : Rc) * 8, 256);
+        plus_idx = o; o = align_up(o + Lc * 4, 256);
+        nb_idx = o; o = align_up(o + Lc * 4, 256);
+        nxt0 = o; o = align_up(o + Lc * 4, 256);
+        nxtA = o; o = align_up(o + Lc * 4, 256);
+        nxtB = o; o = align_up(o + Lc * 4, 256);
+        mark = o; o = align_up(o + Lc, 256);
+        rec_start = o; o = align_up(o + Rc * 4, 256);
+        rec_plus = o; o = align_up(o + Rc * 4, 256);
+        rec_last = o; o = align_up(o + Rc * 4, 256);
+        rec_S = o; o = align_up(o + Rc * 8, 256);
+        end = o;
+    }
+};
+
+uint64_t parse_wrapped_workspace_size(uint64_t text_bytes, uint64_t max_lines, uint64_t max_records)
+{
+    return WrapLayout(ParseLayout(text_bytes, max_lines).end, max_lines, max_records).end;
+}
+
+hipError_t launch_parse_wrapped(const uint8_t* text, uint64_t n, int final, uint8_t* seq, uint8_t* qual, uint64_t seq_capacity,
+                                uint64_t* offsets, uint64_t* name_pos, uint32_t* name_len, uint64_t max_records, void* workspace,
+                                uint64_t max_lines, ParseResult* res, hipStream_t s)
+{
+    uint8_t* ws = static_cast<uint8_t*>(workspace);
+    const ParseLayout lay(n, max_lines);
+    const WrapLayout wl(lay.end, max_lines, max_records);
+    ParseState* st = reinterpret_cast<ParseState*>(ws + lay.state);
+    uint32_t* tile_count = reinterpret_cast<uint32_t*>(ws + lay.tile_count);
+    uint64_t* tile_base = reinterpret_cast<uint64_t*>(ws + lay.tile_base);
+    uint64_t* tile_last = reinterpret_cast<uint64_t*>(ws + lay.tile_last);
+    uint32_t* nl_tile = reinterpret_cast<uint32_t*>(ws + lay.nl_tile);
+    uint64_t* nlpos = reinterpret_cast<uint64_t*>(ws + lay.nlpos);
+    uint64_t* line_start = reinterpret_cast<uint64_t*>(ws + lay.line_start);
+    uint32_t* line_len = reinterpret_cast<uint32_t*>(ws + lay.line_len);
+    uint8_t* line_first = ws + lay.line_head;
+    WrapState* w = reinterpret_cast<WrapState*>(ws + wl.state);
+    uint64_t* total = reinterpret_cast<uint64_t*>(ws + wl.total);
+    uint64_t* tmp = reinterpret_cast<uint64_t*>(ws + wl.tmp);
+    uint64_t* cP = reinterpret_cast<uint64_t*>(ws + wl.cP);
+    uint64_t* cPlus = reinterpret_cast<uint64_t*>(ws + wl.cPlus);
+    uint64_t* cNb = reinterpret_cast<uint64_t*>(ws + wl.cNb);
+    uint64_t* cRid = reinterpret_cast<uint64_t*>(ws + wl.cRid);
+    uint64_t* part = reinterpret_cast<uint64_t*>(ws + wl.part);
+    uint32_t* plus_idx = reinterpret_cast<uint32_t*>(ws + wl.plus_idx);
+    uint32_t* nb_idx = reinterpret_cast<uint32_t*>(ws + wl.nb_idx);
+    uint32_t* nxt0 = reinterpret_cast<uint32_t*>(ws + wl.nxt0);
+    uint32_t* nxtA = reinterpret_cast<uint32_t*>(ws + wl.nxtA);
+    uint32_t* nxtB = reinterpret_cast<uint32_t*>(ws + wl.nxtB);
+    uint8_t* mark = ws + wl.mark;
+    uint32_t* rec_start = reinterpret_cast<uint32_t*>(ws + wl.rec_start);
+    uint32_t* rec_plus = reinterpret_cast<uint32_t*>(ws + wl.rec_plus);
+    uint32_t* rec_last = reinterpret_cast<uint32_t*>(ws + wl.rec_last);
+    uint64_t* rec_S = reinterpret_cast<uint64_t*>(ws + wl.rec_S);
+
+    const uint64_t ntile = (n + TILE - 1) / TILE;
+    const uint32_t gt = (uint32_t)(ntile ? ntile : 1);
+    const uint64_t lines_cap = max_lines < n + 1 ? max_lines : n + 1;
+    const uint64_t cap = lines_cap + 3;                    // the lines, and the three that stand for how a chain ends
+    auto capped = [](uint64_t blocks) { return (uint32_t)(blocks < 1 ? 1 : (blocks > 16384 ? 16384 : blocks)); };
+    const uint32_t gl = capped((lines_cap + PB - 1) / PB), gw = capped((cap + WQ_B - 1) / WQ_B);
+    hipError_t e = hipMemsetAsync(w, 0, sizeof(WrapState), s);
+    if (e == hipSuccess) e = hipMemsetAsync(rec_S, 0, (max_records + 2) * 8, s);
+    if (e != hipSuccess) return e;
+    // the line table as for FASTA, with every line's first byte in place of the head flag
+    hipLaunchKernelGGL(k_nl_index, dim3(gt), dim3(PB), 0, s, text, n, tile_count, tile_last, nl_tile);
+    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, tile_count, ntile, tile_base, &st->n_nl);
+    hipLaunchKernelGGL(k_parse_init, dim3(1), dim3(1), 0, s, st, n, final, text, max_lines);
+    hipLaunchKernelGGL((k_line_table<false>), dim3(gl < 2048 ? gl : 2048), dim3(PB), 0, s, text, n, ntile, nl_tile, tile_count, tile_base,
+                       tile_last, st, nlpos, line_start, line_len, line_first, 1);
+    uint64_t* sums[3] = {cP, cPlus, cNb};
+    for (int kind = 0; kind < 3; kind++) {
+        hipLaunchKernelGGL(k_wq_flags, dim3(gw), dim3(WQ_B), 0, s, st, line_len, line_first, kind, cap, tmp);
+        if ((e = launch_scan64(tmp, cap, sums[kind], part, total, s)) != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k_wq_index, dim3(gw), dim3(WQ_B), 0, s, st, line_len, line_first, cPlus, cNb, cap, plus_idx, nb_idx);
+    hipLaunchKernelGGL(k_wq_next, dim3(gw), dim3(WQ_B), 0, s, st, final, line_len, line_first, cP, cPlus, cNb, plus_idx, nb_idx, cap,
+                       nxt0, nxtA, mark);
+    uint32_t rounds = 1;
+    while ((1ull << rounds) < cap + 1) rounds++;
+    uint32_t *a = nxtA, *b = nxtB;
+    for (uint32_t r = 0; r < rounds; r++) {
+        hipLaunchKernelGGL(k_wq_jump, dim3(gw), dim3(WQ_B), 0, s, st, cap, a, b, mark);
+        uint32_t* t = a; a = b; b = t;
+    }
+    hipLaunchKernelGGL(k_wq_emit, dim3(gw), dim3(WQ_B), 0, s, st, n, final, nlpos, line_start, nxt0, mark, cap, tmp, w);
+    if ((e = launch_scan64(tmp, cap, cRid, part, total, s)) != hipSuccess) return e;       // *total: records
+    hipLaunchKernelGGL(k_wq_records, dim3(gw), dim3(WQ_B), 0, s, st, final, line_len, line_first, line_start, cP, cPlus, cNb, plus_idx,
+                       nb_idx, cRid, tmp, cap, max_records, rec_start, rec_plus, rec_last, rec_S, name_pos, name_len, w);
+    if ((e = launch_scan64(rec_S, max_records + 1, offsets, part, total + 1, s)) != hipSuccess) return e;
+    hipLaunchKernelGGL(k_wq_check, dim3(1), dim3(1), 0, s, st, max_lines, total, offsets, max_records, seq_capacity, w);
+    hipLaunchKernelGGL(k_wq_copy, dim3(capped((lines_cap * 8 + WQ_B - 1) / WQ_B)), dim3(WQ_B), 0, s, st, w, text, line_start, line_len,
+                       cP, cRid, rec_start, rec_plus, rec_last, offsets, cap, seq, qual);
+    hipLaunchKernelGGL(k_wq_finish, dim3(1), dim3(1), 0, s, w, offsets, res);
+    return hipGetLastError();
 }
 
 }  // namespace skh

@@ -79,7 +79,8 @@ def gpu_parse(env, text, fmt, final, max_lines=None, max_records=None, seq_capac
     d_offs = torch.full((max_records + 1,), -1, dtype=torch.int64, device=dev)
     d_npos = torch.zeros(max(max_records, 1), dtype=torch.int64, device=dev)
     d_nlen = torch.zeros(max(max_records, 1), dtype=torch.int32, device=dev)
-    ws_bytes = lib.skh_parse_workspace_size(n, max_lines)
+    ws_bytes = (lib.skh_parse_wrapped_workspace_size(n, max_lines, max_records) if fmt == capi.FASTQ_WRAPPED
+                else lib.skh_parse_workspace_size(n, max_lines))
     d_ws = torch.zeros(ws_bytes + 256, dtype=torch.uint8, device=dev)
     ws_ptr = (d_ws.data_ptr() + 255) & ~255
     d_res = torch.zeros(6, dtype=torch.int64, device=dev)
@@ -97,7 +98,7 @@ def gpu_parse(env, text, fmt, final, max_lines=None, max_records=None, seq_capac
     nlen = d_nlen[:nrec].cpu().numpy()
     names = [text[int(p):int(p) + int(l)] for p, l in zip(npos, nlen)]
     seq = d_seq[:sb].cpu().numpy().tobytes()
-    qual = d_qual[:sb].cpu().numpy().tobytes() if fmt == capi.FASTQ else None
+    qual = d_qual[:sb].cpu().numpy().tobytes() if fmt != capi.FASTA else None
     # nothing may be written past the sequence bytes
     assert bool((d_seq[sb:] == 0xEE).all())
     return res, names, seq, qual, offs
@@ -112,7 +113,7 @@ def records_of(names, seq, qual, offs):
 
 
 def check_text(env, tmp_path, text, fmt, tag):
-    path = str(tmp_path / ("in_%s.%s" % (tag, "fq" if fmt == env["capi"].FASTQ else "fa")))
+    path = str(tmp_path / ("in_%s.%s" % (tag, "fa" if fmt == env["capi"].FASTA else "fq")))
     with open(path, "wb") as fh:
         fh.write(text)
     want = oracle_records(env["ora"], path)
@@ -281,3 +282,85 @@ def test_large_fastq_properties(env):
     assert np.array_equal(offs, np.arange(nrec + 1, dtype=np.uint64) * L)
     assert s == seq.tobytes() and q == qual.tobytes()
     assert names[0] == b"SIM:000000000" and names[-1] == b"SIM:%09d" % (nrec - 1)
+
+
+# ---------------------------------------------------------------- FASTQ with wrapped records
+
+def wrapped_fastq(rng, nrec, crlf, width=None, blank=0.1):
+    """Records whose sequence and quality are wrapped (each at its own width), quality lines that start with
+    '@' and '+', blank lines between records, records without sequence, four-line records among them."""
+    eol = b"\r\n" if crlf else b"\n"
+    parts = []
+    for r in range(nrec):
+        L = int(rng.choice([0, 1, 7, 60, 61, 150, 151, 400, int(rng.integers(0, 3000))]))
+        s = np.frombuffer(b"ACGTN", np.uint8)[rng.integers(0, 5, L)].tobytes()
+        q = rng.integers(33, 75, L, dtype=np.uint8)
+        if L and rng.random() < 0.5:
+            q[rng.integers(0, L, max(1, L // 20))] = rng.choice([ord("@"), ord("+")])
+        q = q.tobytes()
+        ws = width or int(rng.choice([1, 13, 60, 70, 1 << 30]))
+        wq = width or int(rng.choice([1, 17, 60, 70, 1 << 30]))
+        parts.append(b"@read%d some text" % r + eol)
+        for a in range(0, L, ws):
+            parts.append(s[a:a + ws] + eol)
+        parts.append((b"+" if r % 3 else b"+read%d" % r) + eol)
+        for a in range(0, L, wq):
+            parts.append(q[a:a + wq] + eol)
+        if rng.random() < blank:
+            parts.append(eol * int(rng.integers(1, 3)))
+    return b"".join(parts)
+
+
+@pytest.mark.parametrize("crlf", [False, True])
+def test_wrapped_fastq_whole_and_blockwise(env, tmp_path, crlf):
+    capi = env["capi"]
+    rng = np.random.default_rng(40 + crlf)
+    text = wrapped_fastq(rng, 2500, crlf)
+    path = str(tmp_path / "w.fq")
+    open(path, "wb").write(text)
+    want = oracle_records(env["ora"], path)
+    assert len(want) == 2500
+    res, names, seq, qual, offs = gpu_parse(env, text, capi.FASTQ_WRAPPED, True)
+    assert res.status == capi.PARSE_OK and res.wrapped == 1 and res.consumed == len(text), (res.status, res.consumed)
+    assert records_of(names, seq, qual, offs) == want
+    for block in (3000, 50_000, 1 << 20):
+        got, pos, carry = [], 0, b""
+        while True:
+            chunk = text[pos:pos + block]
+            pos += len(chunk)
+            final = pos >= len(text)
+            buf = carry + chunk
+            res, names, seq, qual, offs = gpu_parse(env, buf, capi.FASTQ_WRAPPED, final)
+            assert res.status == capi.PARSE_OK, (block, pos, res.status)
+            got += records_of(names, seq, qual, offs)
+            carry = buf[res.consumed:]
+            if final:
+                assert res.consumed == len(buf)
+                break
+            assert len(carry) < 4 * 3100 * 2 + 3 * block, "no progress"
+        assert got == want, block
+
+
+def test_wrapped_fastq_four_line_text_and_errors(env, tmp_path):
+    capi = env["capi"]
+    rng = np.random.default_rng(5)
+    text = random_fastq(rng, 1000, False)
+    path = str(tmp_path / "p.fq")
+    open(path, "wb").write(text)
+    res, names, seq, qual, offs = gpu_parse(env, text, capi.FASTQ_WRAPPED, True)
+    assert res.status == capi.PARSE_OK          # (wrapped = 1: it holds records without bases, whose quality line is blank)
+    assert records_of(names, seq, qual, offs) == oracle_records(env["ora"], path)
+    plain = b"".join(b"@r%d\n%s\n+\n%s\n" % (i, b"ACGT" * (1 + i % 40), b"I@+J" * (1 + i % 40)) for i in range(3000))
+    res = gpu_parse(env, plain, capi.FASTQ_WRAPPED, True)[0]
+    assert res.status == capi.PARSE_OK and res.nrec == 3000 and res.wrapped == 0
+    for bad in (b"@r\nACGT\nAC\n+\nIIII\nIII\n",        # more quality than sequence
+                b"ACGT\n@r\nAC\n+\nII\n",                  # text before the first record
+                b"@r\nACGT\n+\nII\n",                      # the file ends inside a record
+                b"@r\nACGT\n+\nIIII\nxx\n"):               # a line that is no '@' line where a record must start
+        res = gpu_parse(env, bad, capi.FASTQ_WRAPPED, True)[0]
+        assert res.status == capi.PARSE_EFORMAT and res.error_line == -1, bad
+    # not final: the record at the end is left for the next block
+    res, names, seq, qual, offs = gpu_parse(env, b"@a\nAC\nGT\n+\nII\nII\n@b\nACGT\n+\nII\n", capi.FASTQ_WRAPPED, False)
+    assert res.status == capi.PARSE_OK and res.nrec == 1 and res.consumed == 17 and seq == b"ACGT" and qual == b"IIII"
+    res = gpu_parse(env, b"", capi.FASTQ_WRAPPED, True)[0]
+    assert res.status == capi.PARSE_OK and res.nrec == 0
