@@ -280,6 +280,22 @@ FastqNorm normalize_fastq(const uint8_t* text, uint64_t n, bool final, std::vect
     }
 }
 
+// Wrapped FASTQ is parsed on the GPU (SKH_FASTQ_WRAPPED) once the four-line parser has refused a block; the
+// serial rewrite above remains for what that parser refuses too -- it names the offending line.
+// SKH_FASTQ_REWRITE=host: the serial rewrite only (as before the GPU form existed); =off: never the serial
+// rewrite (format errors of wrapped text then come without a line number).
+enum { REWRITE_AUTO = 0, REWRITE_HOST = 1, REWRITE_OFF = 2 };
+static int fastq_rewrite_mode()
+{
+    static const int mode = [] {
+        const char* v = getenv("SKH_FASTQ_REWRITE");
+        if (v && !strcmp(v, "host")) return (int)REWRITE_HOST;
+        if (v && !strcmp(v, "off")) return (int)REWRITE_OFF;
+        return (int)REWRITE_AUTO;
+    }();
+    return mode;
+}
+
 // ---- file text in blocks, parsed on the GPU ------------------------------------------------
 //
 // Reads a file (plain or gzip, "-" = stdin) block by block into the pinned buffer of a text
@@ -346,15 +362,26 @@ public:
             }
             PhaseTimer pt(1);
             const bool was_multiline = multiline_;
+            block_wrapped_ = false;
             if (!multiline_) {
-                if (skh_text_parse(ctx_, t_, have_, fastq_ ? SKH_FASTQ : SKH_FASTA, eof_, &res) != SKH_OK) {
+                const int fmt = fastq_ ? (wrapped_gpu_ ? SKH_FASTQ_WRAPPED : SKH_FASTQ) : SKH_FASTA;
+                if (skh_text_parse(ctx_, t_, have_, fmt, eof_, &res) != SKH_OK) {
                     err_ = skh_last_error();
                     return false;
                 }
-                if (fastq_ && (res.status == SKH_PARSE_EFORMAT || (res.nrec == 0 && (buf[0] == '\n' || buf[0] == '\r')))) multiline_ = true;
-                else if (res.status == SKH_PARSE_EFORMAT) {
-                    err_ = "error when parsing " + path_ + ": invalid FASTA/Q format near line " +
-                           std::to_string(lines_before_ + (uint64_t)res.error_line + 1);
+                bool refused = fastq_ && (res.status == SKH_PARSE_EFORMAT || (res.nrec == 0 && (buf[0] == '\n' || buf[0] == '\r')));
+                if (fmt == SKH_FASTQ_WRAPPED && res.status == SKH_PARSE_OK) { block_wrapped_ = true; refused = false; }
+                else if (refused && fmt == SKH_FASTQ && fastq_rewrite_mode() != REWRITE_HOST) {
+                    // records wrapped over several lines, blank lines between records: the GPU's other parser
+                    skh_parse_result r2;
+                    if (skh_text_parse(ctx_, t_, have_, SKH_FASTQ_WRAPPED, eof_, &r2) != SKH_OK) { err_ = skh_last_error(); return false; }
+                    if (r2.status == SKH_PARSE_OK) { res = r2; block_wrapped_ = true; refused = false; }
+                }
+                if (block_wrapped_) wrapped_gpu_ = res.wrapped != 0 || res.nrec == 0;      // plain blocks go back to the fast parser
+                if (refused && fastq_rewrite_mode() != REWRITE_OFF) multiline_ = true;
+                else if (refused || res.status == SKH_PARSE_EFORMAT) {
+                    err_ = "error when parsing " + path_ + ": invalid FASTA/Q format" +
+                           (res.error_line >= 0 ? " near line " + std::to_string(lines_before_ + (uint64_t)res.error_line + 1) : std::string());
                     return false;
                 }
             }
@@ -363,7 +390,7 @@ public:
                 // wrapped FASTQ records: the block's text is kept aside, its four-line form is parsed
                 orig_.assign(buf, buf + have_);
                 const FastqNorm nr = normalize_fastq(orig_.data(), have_, eof_, norm_);
-                if (!was_multiline && !nr.wrapped && res.status == SKH_PARSE_EFORMAT) {
+                if (!was_multiline && !nr.wrapped && res.status == SKH_PARSE_EFORMAT && res.error_line >= 0) {
                     // plain four-line text as far as the serial scan got: the GPU parser's finding stands
                     err_ = "error when parsing " + path_ + ": invalid FASTA/Q format near line " +
                            std::to_string(lines_before_ + (uint64_t)res.error_line + 1);
@@ -421,7 +448,7 @@ public:
     void advance(const skh_parse_result& res)
     {
         uint8_t* buf = skh_text_buffer(t_);
-        lines_before_ += (fastq_ && !multiline_) ? res.nrec * 4 : res.lines;      // for error messages ("near line")
+        lines_before_ += (fastq_ && !multiline_ && !block_wrapped_) ? res.nrec * 4 : res.lines;      // for error messages ("near line")
         if (multiline_) memcpy(buf, orig_.data() + consumed_, have_ - consumed_);  // the buffer holds the rewritten text
         else memmove(buf, buf + consumed_, have_ - consumed_);
         have_ -= consumed_;
@@ -442,6 +469,7 @@ private:
     uint64_t have_ = 0, consumed_ = 0, lines_before_ = 0;
     bool eof_ = false, done_ = false, format_known_ = false, fastq_ = false, any_ = false;
     bool multiline_ = false, eof_hold_ = false;            // FASTQ with wrapped records (normalize_fastq)
+    bool wrapped_gpu_ = false, block_wrapped_ = false;     // ... parsed on the GPU: the next block starts with that parser / this block was
     std::vector<uint8_t> orig_, norm_;                     // the block's own text / its four-line form
 };
 
@@ -648,6 +676,7 @@ private:
         uint64_t acc_off = 0, acc_have = 0;                 // where its text lies
         bool format_known = false;
         bool multiline = false;                             // FASTQ with wrapped records: blocks are rewritten (normalize_fastq)
+        bool wrapped_gpu = false;                           // ... or parsed by the GPU's parser of wrapped FASTQ, from the next block on
         std::vector<uint8_t> norm;
         uint64_t lines_before = 0;
         // the blocks go round in the order they are made: dealt to the GPUs in turn
@@ -728,22 +757,40 @@ private:
             }
             skh_parse_result res;
             bool rewrite = multiline;                // this block goes through normalize_fastq
+            bool block_wrapped = false;              // ... or was parsed by the GPU's parser of wrapped FASTQ
             if (!multiline) {
                 PhaseTimer pt(1);
-                if (skh_text_parse_at(b->ctx, b->t, off, have, s.fastq ? SKH_FASTQ : SKH_FASTA, eof, &res) != SKH_OK) {
+                const int fmt = s.fastq ? (wrapped_gpu ? SKH_FASTQ_WRAPPED : SKH_FASTQ) : SKH_FASTA;
+                if (skh_text_parse_at(b->ctx, b->t, off, have, fmt, eof, &res) != SKH_OK) {
                     s.fail(skh_last_error());
                     break;
                 }
                 // (the host's copy of the text is intact)  A block that starts with a blank line holds no
-                // four-line record for the GPU parser either: blank lines between records are the serial
-                // scan's business too.
-                if (s.fastq && (res.status == SKH_PARSE_EFORMAT ||
-                                (res.nrec == 0 && (buf[off] == '\n' || buf[off] == '\r')))) rewrite = true;
+                // four-line record for the four-line parser either; wrapped records and blank lines between
+                // records go to the GPU's parser of wrapped FASTQ, and what that one refuses to the serial scan,
+                // which names the line.
+                bool refused = s.fastq && (res.status == SKH_PARSE_EFORMAT ||
+                                           (res.nrec == 0 && (buf[off] == '\n' || buf[off] == '\r')));
+                if (fmt == SKH_FASTQ_WRAPPED && res.status == SKH_PARSE_OK) { block_wrapped = true; refused = false; }
+                else if (refused && fmt == SKH_FASTQ && fastq_rewrite_mode() != REWRITE_HOST) {
+                    skh_parse_result r2;
+                    if (skh_text_parse_at(b->ctx, b->t, off, have, SKH_FASTQ_WRAPPED, eof, &r2) != SKH_OK) { s.fail(skh_last_error()); break; }
+                    if (r2.status == SKH_PARSE_OK) { res = r2; block_wrapped = true; refused = false; }
+                }
+                if (block_wrapped) wrapped_gpu = res.wrapped != 0 || res.nrec == 0;    // plain blocks go back to the fast parser
+                if (refused) {
+                    if (fastq_rewrite_mode() != REWRITE_OFF) rewrite = true;
+                    else {
+                        s.fail("error when parsing " + s.path + ": invalid FASTA/Q format" +
+                               (res.error_line >= 0 ? " near line " + std::to_string(lines_before + (uint64_t)res.error_line + 1) : std::string()));
+                        break;
+                    }
+                }
             }
             uint64_t consumed = 0, lines = 0;
             if (rewrite) {
                 const FastqNorm nr = normalize_fastq(buf + off, have, eof, norm);
-                if (!multiline && !nr.wrapped && res.status == SKH_PARSE_EFORMAT) {
+                if (!multiline && !nr.wrapped && res.status == SKH_PARSE_EFORMAT && res.error_line >= 0) {
                     // plain four-line text as far as the serial scan got: the GPU parser's finding stands, a
                     // malformed record does not send the rest of the file through the serial rewrite
                     s.fail("error when parsing " + s.path + ": invalid FASTA/Q format near line " +
@@ -775,7 +822,7 @@ private:
                     acc = b; acc_off = off; acc_have = have;       // nothing complete yet: more text is needed
                     continue;
                 }
-                consumed = res.consumed; lines = s.fastq ? res.nrec * 4 : res.lines;
+                consumed = res.consumed; lines = (s.fastq && !block_wrapped) ? res.nrec * 4 : res.lines;
             }
             if (!eof) {
                 PhaseTimer pt(6);

@@ -283,7 +283,8 @@ int skh_text_parse_at(skh_ctx* cx, skh_text* t, uint64_t off, uint64_t n, int fo
     if (!t || !res) return fail(SKH_EINVAL, "NULL argument");
     if (t->ctx != cx) return fail(SKH_EINVAL, "the text block belongs to another context");
     if (off > t->cap || n > t->cap - off) return fail(SKH_ECAPACITY, "text block larger than its buffer");
-    if (format != SKH_FASTA && format != SKH_FASTQ) return fail(SKH_EINVAL, "format must be SKH_FASTA or SKH_FASTQ");
+    if (format != SKH_FASTA && format != SKH_FASTQ && format != SKH_FASTQ_WRAPPED)
+        return fail(SKH_EINVAL, "format must be SKH_FASTA, SKH_FASTQ or SKH_FASTQ_WRAPPED");
     // the "device" text: what was uploaded ahead plus the bytes around it, as the library composes it
     t->text.assign(n, 0);
     const uint64_t end = off + n;
@@ -346,6 +347,40 @@ int skh_text_parse_at(skh_ctx* cx, skh_text* t, uint64_t off, uint64_t n, int fo
                     t->seq.insert(t->seq.end(), x + lines[i].start, x + lines[i].start + lines[i].len);
             }
         }
+    } else if (format == SKH_FASTQ_WRAPPED) {
+        // records wrapped over several lines, blank lines between records: a serial walk over the line table by the
+        // rules of the library's header; what is not such text is a format error without a line number
+        uint64_t i = 0;
+        bool broken = false, wrapped = false;
+        consumed = final ? n : start_of_line(L);
+        uint64_t lines_used = L;
+        for (;;) {
+            const uint64_t i_before = i;
+            while (i < L && lines[i].len == 0) i++;
+            if (i == L) break;
+            const uint64_t start = i;
+            auto cut = [&]() { if (final) broken = true; else { consumed = lines[start].start; lines_used = start; } };
+            if (x[lines[i].start] != '@') { broken = true; break; }
+            uint64_t j = i + 1;
+            while (j < L && !(lines[j].len && x[lines[j].start] == '+')) j++;
+            if (j == L) { cut(); break; }
+            uint64_t S = 0, Q = 0, k = j;
+            for (uint64_t a = i + 1; a < j; a++) S += lines[a].len;
+            while (Q < S && k + 1 < L) { k++; Q += lines[k].len; }
+            if (Q < S) { cut(); break; }
+            if (Q != S) { broken = true; break; }
+            t->offs.push_back(t->seq.size());
+            t->npos.push_back(lines[start].start + 1);
+            t->nlen.push_back(lines[start].len - 1);
+            for (uint64_t a = i + 1; a < j; a++) t->seq.insert(t->seq.end(), x + lines[a].start, x + lines[a].start + lines[a].len);
+            for (uint64_t a = j + 1; a <= k; a++) t->qual.insert(t->qual.end(), x + lines[a].start, x + lines[a].start + lines[a].len);
+            if (j != start + 2 || k != j + 1 || start != i_before || (nrec == 0 && start != 0)) wrapped = true;
+            nrec++;
+            i = k + 1;
+        }
+        if (broken) { bad = 0; }
+        res->wrapped = wrapped ? 1 : 0;
+        res->lines = lines_used;
     } else {
         uint64_t Leff = L, fbh = ~0ull, last_nonblank = 0;
         bool any_nonblank = false;
@@ -381,13 +416,13 @@ int skh_text_parse_at(skh_ctx* cx, skh_text* t, uint64_t off, uint64_t n, int fo
         }
     }
     if (bad >= 0) {
-        res->status = SKH_PARSE_EFORMAT; res->error_line = bad;
+        res->status = SKH_PARSE_EFORMAT; res->error_line = format == SKH_FASTQ_WRAPPED ? -1 : bad;
         t->seq.clear(); t->qual.clear(); t->offs.clear(); t->npos.clear(); t->nlen.clear();
         nrec = 0;
     }
     t->offs.push_back(t->seq.size());
     res->nrec = nrec; res->seq_bytes = t->seq.size(); res->consumed = consumed;
-    t->fastq = format == SKH_FASTQ;
+    t->fastq = format != SKH_FASTA;
     t->nrec = nrec;
     t->transformed = t->gaps_removed = t->letters_ready = t->names_external = false;
     t->filter_offs.clear();
@@ -724,6 +759,11 @@ int skh_comm_init_rank(skh_ctx* ctx, const uint8_t*, int nranks, int rank, skh_c
 }
 void skh_comm_destroy(skh_comm* c) { delete c; }
 int skh_comm_local_ranks(const skh_comm* c) { return c ? (int)c->ctx.size() : 0; }
+uint64_t skh_parse_wrapped_workspace_size(uint64_t text_bytes, uint64_t max_lines, uint64_t max_records)
+{
+    return 256 + text_bytes + 64 * (max_lines + max_records);
+}
+
 int skh_kernel_for(skh_ctx* ctx, int op, uint64_t, uint64_t, int, char* name, uint64_t name_bytes)
 {
     if (!ctx || !name || op < SKH_OP_REVCOMP || op > SKH_OP_COUNT || name_bytes < 9) return SKH_EINVAL;

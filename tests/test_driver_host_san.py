@@ -76,8 +76,13 @@ def test_long_records_and_several_files(san, oracle_cli, which, tmp_path):
         assert got[0] == want[0] == 0 and got[1] == want[1], argv
 
 
+@pytest.mark.parametrize("rewrite", ["auto", "host"])
 @pytest.mark.parametrize("which", ["asan", "tsan"])
-def test_multiline_fastq(san, oracle_cli, which, tmp_path):
+def test_multiline_fastq(san, oracle_cli, which, tmp_path, rewrite, monkeypatch):
+    # auto: the library's parser of wrapped FASTQ (here the stub's) with the serial rewrite behind it; host: the
+    # serial rewrite alone
+    if rewrite != "auto":
+        monkeypatch.setenv("SKH_FASTQ_REWRITE", rewrite)
     variants = {"wrapped": dict(), "late": dict(four_line_head=1500), "crlf": dict(crlf=True, width=37)}
     for name, kw in variants.items():
         f = str(tmp_path / (name + ".fq"))
@@ -95,7 +100,10 @@ def test_multiline_fastq(san, oracle_cli, which, tmp_path):
     assert got[0] == 0 and got[1] == want[1]
 
 
-def test_multiline_fastq_small_cases(san, oracle_cli):
+@pytest.mark.parametrize("rewrite", ["auto", "host", "off"])
+def test_multiline_fastq_small_cases(san, oracle_cli, rewrite, monkeypatch):
+    if rewrite != "auto":
+        monkeypatch.setenv("SKH_FASTQ_REWRITE", rewrite)
     cases = ["@r1\nACGT\nAC\n+\nIIII\nII\n", "@r1\nACGT\nAC\n+r1\n@III\n+I\n@r2\nAC\n+\nII", "@e\n+\n@r2\nAC\nGT\n+\nIIII\n",
              "\n\n@r1\nAC\n\nGT\n+\nII\nII\n\n", "@a\nAC\n+\nII\n\n\n@b\nACG\n+\nIII\n"]
     for text in cases:

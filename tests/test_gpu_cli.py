@@ -91,10 +91,18 @@ MULTILINE_COMMANDS = [["seq"], ["seq", "-r", "-p", "-w", "0"], ["seq", "-r", "-p
                       ["subseq", "-r", "3:-3"], ["convert", "--to", "Illumina-1.5+"]]
 
 
+# who reads wrapped FASTQ: the GPU's parser of such text with the serial rewrite behind it for what it refuses (the
+# default), the serial rewrite alone, the GPU's parser alone
+REWRITE_MODES = ["auto", "host", "off"]
+
+
+@pytest.mark.parametrize("rewrite", REWRITE_MODES)
 @pytest.mark.parametrize("argv", MULTILINE_COMMANDS, ids=lambda v: " ".join(v))
-def test_multiline_fastq_default_path(cli, oracle_cli, argv, tmp_path):
+def test_multiline_fastq_default_path(cli, oracle_cli, argv, tmp_path, rewrite, monkeypatch):
     # README.md:88, doc/docs/usage.md:357-359 of the reference: multi-line FASTQ is read like any other;
     # here without any flag, from files and from standard input, whatever the block size
+    if rewrite != "auto":
+        monkeypatch.setenv("SKH_FASTQ_REWRITE", rewrite)
     variants = {"wrapped": dict(), "late": dict(four_line_head=1500), "crlf": dict(crlf=True, width=37)}
     for name, kw in variants.items():
         f = str(tmp_path / (name + ".fq"))
@@ -111,7 +119,10 @@ def test_multiline_fastq_default_path(cli, oracle_cli, argv, tmp_path):
         assert got[0] == 0 and got[1] == want_stdin[1], name
 
 
-def test_multiline_fastq_small_cases(cli, oracle_cli):
+@pytest.mark.parametrize("rewrite", REWRITE_MODES)
+def test_multiline_fastq_small_cases(cli, oracle_cli, rewrite, monkeypatch):
+    if rewrite != "auto":
+        monkeypatch.setenv("SKH_FASTQ_REWRITE", rewrite)
     cases = ["@r1\nACGT\nAC\n+\nIIII\nII\n",                       # the documented shape
              "@r1\nACGT\nAC\n+r1\n@III\n+I\n@r2\nAC\n+\nII",         # quality lines starting with '@' / '+', no final newline
              "@e\n+\n@r2\nAC\nGT\n+\nIIII\n",                        # a record without any sequence line
