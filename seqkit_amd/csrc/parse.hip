@@ -61,7 +61,9 @@ __device__ __forceinline__ uint32_t nl_mask16(uint4 v)       // bit k set: byte 
         const uint32_t x = w[d] ^ 0x0a0a0a0au;              // zero byte where '\n'
         // exact zero-byte detector: 0x80 in every byte of x that is zero, nothing elsewhere
         const uint32_t z = ~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x | 0x7f7f7f7fu);
-        m |= (((z >> 7) & 1u) | ((z >> 14) & 2u) | ((z >> 21) & 4u) | ((z >> 28) & 8u)) << (4 * d);
+        // the four flags (bits 7, 15, 23, 31) to bits 0..3: two folds instead of four extractions
+        const uint32_t t = z >> 7, u = t | (t >> 7);
+        m |= ((u | (u >> 14)) & 0xfu) << (4 * d);
     }
     return m;
 }

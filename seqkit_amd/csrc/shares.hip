@@ -384,6 +384,7 @@ void worker_main(Worker* wp)
         }
         w.rc = rc;
         w.err = rc ? skh_last_error() : "";
+        if (rc) { (void)hipStreamSynchronize(w.st[0]); (void)hipStreamSynchronize(w.st[1]); }   // nothing of a failed job stays in flight on the caller's batch
         w.info.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         {
             std::lock_guard<std::mutex> l(m->mu);
