@@ -364,3 +364,15 @@ def test_wrapped_fastq_four_line_text_and_errors(env, tmp_path):
     assert res.status == capi.PARSE_OK and res.nrec == 1 and res.consumed == 17 and seq == b"ACGT" and qual == b"IIII"
     res = gpu_parse(env, b"", capi.FASTQ_WRAPPED, True)[0]
     assert res.status == capi.PARSE_OK and res.nrec == 0
+
+
+def test_wrapped_fastq_capacity_errors(env):
+    capi = env["capi"]
+    text = b"@a\nAC\nGT\n+\nII\nII\n@b\nACG\n+\nIII\n@c\nA\n+\nI\n"
+    W = capi.FASTQ_WRAPPED
+    assert gpu_parse(env, text, W, True)[0].nrec == 3
+    assert gpu_parse(env, text, W, True, max_lines=5)[0].status == capi.PARSE_ECAPACITY
+    assert gpu_parse(env, text, W, True, max_records=2)[0].status == capi.PARSE_ECAPACITY
+    assert gpu_parse(env, text, W, True, seq_capacity=7)[0].status == capi.PARSE_ECAPACITY
+    res, names, seq, qual, offs = gpu_parse(env, text, W, True, max_records=3, seq_capacity=8)
+    assert res.status == capi.PARSE_OK and seq == b"ACGTACGA" and qual == b"IIIIIIII" and names == [b"a", b"b", b"c"]
