@@ -269,6 +269,8 @@ int skh_subseq_dev(skh_ctx *ctx, const uint8_t *d_seq, const uint8_t *d_qual, co
  * block needed this format.  Which '@' lines start records is found by following, from the first line, the line
  * each record would end at (pointer doubling over the line table).  Text that is not such FASTQ -- and a record cut
  * short by the end of the file -- is SKH_PARSE_EFORMAT with error_line = -1: this format does not name the line.
+ * (A head line with nothing but blank lines between it and the end of the file is a record without bases, as a head
+ * followed by a '+' line is.)
  * The workspace is skh_parse_wrapped_workspace_size(text_bytes, max_lines, max_records) bytes. */
 #define SKH_FASTQ_WRAPPED 3
 #define SKH_PARSE_OK        0

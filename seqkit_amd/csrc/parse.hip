@@ -406,6 +406,8 @@ __global__ __launch_bounds__(PB) void k_line_table(const uint8_t* __restrict__ t
                         else bad = c != '@';
                     } else if (role == 2) {
                         bad = c != '+';
+                    } else if (role == 1) {
+                        bad = len != 0 && c == '+';          // the reader takes such a line for the '+' line: not four-line text
                     }                                        // role 3 (equal lengths) is checked by k_line_partials
                 }
                 if (len) { last = i > last ? i : last; any = true; }
@@ -1046,13 +1048,22 @@ __device__ __forceinline__ bool wq_record(uint64_t i, uint64_t L, int final, con
     const uint32_t cut = (uint32_t)(final ? L + 2 : L + 1);
     if (line_len[i] == 0 || line_first[i] != '@') { why = (uint32_t)(L + 2); return false; }
     const uint64_t j = plus_idx[cPlus[i + 1]];
-    if (j >= L) { why = cut; return false; }
+    if (j >= L) {
+        // no '+' line any more: where the file ends, a head with nothing but blank lines behind it is a record
+        // without bases (the reader restated from the reference takes it so); bases without quality are not
+        if (final && cP[L] == cP[i + 1]) { plus = L; last = L - 1; return true; }
+        why = cut; return false;
+    }
     const uint64_t S = cP[j] - cP[i + 1];
     plus = j; last = j;
     if (S == 0) return true;
     const uint64_t q0 = cP[j + 1];
     if (cP[L] - q0 < S) { why = cut; return false; }
-    uint64_t lo = j + 1, hi = L - 1;                      // smallest k with cP[k + 1] - q0 >= S
+    // smallest k with cP[k + 1] - q0 >= S: the quality is as many lines as the sequence or so, so the search gallops
+    // from the '+' line (1, 2, 4, ... lines on) before it halves what is left
+    uint64_t lo = j + 1, hi = L - 1, step = 1;
+    while (lo + step - 1 < hi && cP[lo + step] - q0 < S) { lo += step; step <<= 1; }        // (k = lo + step - 1 is too small)
+    if (lo + step - 1 < hi) hi = lo + step - 1;
     while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (cP[mid + 1] - q0 >= S) hi = mid; else lo = mid + 1; }
     if (cP[lo + 1] - q0 != S) { why = (uint32_t)(L + 2); return false; }       // more quality than sequence
     last = lo;
@@ -1149,7 +1160,8 @@ __global__ void k_wq_check(const ParseState* st, uint64_t max_lines, const uint6
     if (w->status == PARSE_OK && (nrec > max_records || offsets[nrec] > seq_capacity)) w->status = PARSE_ECAPACITY;
 }
 
-// every sequence and quality line to its place: 8 lanes per line
+// every sequence and quality line to its place: a lane looks up where its line goes (64 lines per wavefront at a
+// time, their lookups in flight together), then 8 lanes copy a line
 __global__ __launch_bounds__(WQ_B) void k_wq_copy(const ParseState* st, const WrapState* w, const uint8_t* __restrict__ text,
                                                   const uint64_t* __restrict__ line_start, const uint32_t* __restrict__ line_len,
                                                   const uint64_t* __restrict__ cP, const uint64_t* __restrict__ cRid,
@@ -1159,17 +1171,33 @@ __global__ __launch_bounds__(WQ_B) void k_wq_copy(const ParseState* st, const Wr
 {
     if (w->status != PARSE_OK) return;
     const uint64_t L = st->nlines;
-    const uint32_t j = threadIdx.x & 7;
-    for (uint64_t i = ((uint64_t)blockIdx.x * WQ_B + threadIdx.x) >> 3; i < L && i < cap; i += ((uint64_t)gridDim.x * WQ_B) >> 3) {
-        const uint64_t before = cRid[i + 1];              // records that start at or before line i
-        const uint32_t len = line_len[i];
-        if (before == 0 || len == 0) continue;
-        const uint64_t r = before - 1;
-        const uint64_t start = rec_start[r], plus = rec_plus[r], last = rec_last[r];
-        if (i == start || i == plus || i > last) continue;
-        const bool is_q = i > plus;
-        const uint64_t dst = offsets[r] + (cP[i] - cP[(is_q ? plus : start) + 1]);
-        copy_line<8>((is_q ? qual : seq) + dst, text + line_start[i], len, j);
+    const uint32_t lane = threadIdx.x & 63, j = lane & 7, grp = lane >> 3;
+    const uint64_t wave0 = ((uint64_t)blockIdx.x * WQ_B + threadIdx.x) >> 6, nwave = ((uint64_t)gridDim.x * WQ_B) >> 6;
+    for (uint64_t base = wave0 * 64; base < L && base < cap; base += nwave * 64) {      // wave-uniform
+        const uint64_t i = base + lane;
+        uint64_t src = 0, dst = 0;
+        uint32_t len = 0, is_q = 0;
+        if (i < L && i < cap) {
+            const uint64_t before = cRid[i + 1];          // records that start at or before line i
+            const uint32_t l = line_len[i];
+            if (before != 0 && l != 0) {
+                const uint64_t r = before - 1;
+                const uint64_t start = rec_start[r], plus = rec_plus[r], last = rec_last[r];
+                if (i != start && i != plus && i <= last) {
+                    is_q = i > plus ? 1u : 0u;
+                    dst = offsets[r] + (cP[i] - cP[(is_q ? plus : start) + 1]);
+                    src = line_start[i];
+                    len = l;
+                }
+            }
+        }
+#pragma unroll 1
+        for (uint32_t r8 = 0; r8 < 8; r8++) {
+            const uint32_t from = r8 * 8 + grp;
+            const uint32_t ll = (uint32_t)__shfl((int)len, (int)from), qq = (uint32_t)__shfl((int)is_q, (int)from);
+            const uint64_t ss = shfl64(src, from), dd = shfl64(dst, from);
+            if (ll) copy_line<8>((qq ? qual : seq) + dd, text + ss, ll, j);
+        }
     }
 }
 

@@ -363,7 +363,18 @@ int skh_text_parse_at(skh_ctx* cx, skh_text* t, uint64_t off, uint64_t n, int fo
             if (x[lines[i].start] != '@') { broken = true; break; }
             uint64_t j = i + 1;
             while (j < L && !(lines[j].len && x[lines[j].start] == '+')) j++;
-            if (j == L) { cut(); break; }
+            if (j == L) {
+                uint64_t rest = 0;
+                for (uint64_t a = i + 1; a < L; a++) rest += lines[a].len;
+                if (!(final && rest == 0)) { cut(); break; }
+                // a head with nothing but blank lines up to the end of the file: a record without bases
+                t->offs.push_back(t->seq.size());
+                t->npos.push_back(lines[start].start + 1);
+                t->nlen.push_back(lines[start].len - 1);
+                wrapped = true;
+                nrec++;
+                break;
+            }
             uint64_t S = 0, Q = 0, k = j;
             for (uint64_t a = i + 1; a < j; a++) S += lines[a].len;
             while (Q < S && k + 1 < L) { k++; Q += lines[k].len; }
@@ -391,6 +402,7 @@ int skh_text_parse_at(skh_ctx* cx, skh_text* t, uint64_t off, uint64_t n, int fo
             bool b = false;
             if (role == 0) { if (lines[i].len == 0) { if (fbh == ~0ull) fbh = i; } else b = c != '@'; }
             else if (role == 2) b = c != '+';
+            else if (role == 1) b = lines[i].len != 0 && c == '+';
             else if (role == 3) b = lines[i].len != lines[i - 2].len;
             if (lines[i].len) { last_nonblank = i; any_nonblank = true; }
             if (b && err < 0) err = (int64_t)i;

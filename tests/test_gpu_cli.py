@@ -139,6 +139,92 @@ def test_multiline_fastq_small_cases(cli, oracle_cli, rewrite, monkeypatch):
         assert rc == 255 and b"[ERRO]" in err
 
 
+@pytest.mark.parametrize("rewrite", REWRITE_MODES)
+def test_multiline_fastq_damaged_texts(cli, oracle_cli, rewrite, monkeypatch):
+    """Wrapped FASTQ with a line deleted, doubled, inserted or re-headed, or cut at a byte: the driver fails where the
+    oracle's CLI fails (exit status 255) and prints the same records where it does not, whoever reads the text."""
+    import numpy as np
+    if rewrite != "auto":
+        monkeypatch.setenv("SKH_FASTQ_REWRITE", rewrite)
+    rng = np.random.default_rng(123)
+    n_ok = n_bad = 0
+    for case in range(150):
+        lines = []
+        for r in range(int(rng.integers(1, 5))):
+            L = int(rng.choice([0, 1, 7, 60, 61, 150]))
+            s = "".join("ACGTN"[i] for i in rng.integers(0, 5, L))
+            q = "".join(chr(c) for c in rng.choice([33, 43, 64, 70, 73], L))
+            ws, wq = int(rng.choice([1, 13, 60, 1000])), int(rng.choice([1, 17, 60, 1000]))
+            lines.append("@read%d some text" % r)
+            lines += [s[a:a + ws] for a in range(0, L, ws)]
+            lines.append("+")
+            lines += [q[a:a + wq] for a in range(0, L, wq)]
+            if rng.random() < 0.3:
+                lines.append("")
+        kind, k = case % 6, int(rng.integers(0, len(lines)))
+        if kind == 0:
+            del lines[k]
+        elif kind == 1:
+            lines.insert(k, lines[k])
+        elif kind == 2:
+            lines.insert(k, ["@x y", "+", "ACGT", "", "+@+@"][int(rng.integers(0, 5))])
+        elif kind == 3 and lines[k]:
+            lines[k] = "@+A"[int(rng.integers(0, 3))] + lines[k][1:]
+        text = "\n".join(lines) + "\n"
+        if kind == 4:
+            text = text[:int(rng.integers(0, len(text) + 1))]
+        want = run_cli(oracle_cli, ["seq", "-r", "-p"], stdin=text)
+        for mode in MODES if rewrite == "auto" else MODES[:1]:
+            got = run_cli(cli, ["seq", "-r", "-p"] + mode, stdin=text)
+            assert want[0] in (0, 255) and got[0] == want[0], (case, kind, mode, text, got[2])
+            if want[0] == 0:
+                assert got[1] == want[1], (case, kind, mode, text)
+            else:
+                assert b"[ERRO]" in got[2]
+        n_ok += want[0] == 0
+        n_bad += want[0] != 0
+    assert n_ok >= 30 and n_bad >= 30, (n_ok, n_bad)
+
+
+def test_fasta_damaged_texts(cli, oracle_cli):
+    """The same for FASTA: lines deleted, doubled, inserted, re-headed ('>', '@', ';', a base), text cut at a byte."""
+    import numpy as np
+    rng = np.random.default_rng(321)
+    n_ok = n_bad = 0
+    for case in range(150):
+        lines = []
+        for r in range(int(rng.integers(1, 5))):
+            L = int(rng.choice([0, 1, 7, 60, 61, 150]))
+            s = "".join("ACGTN>@"[i] for i in rng.choice(7, L, p=[.23, .23, .23, .23, .04, .02, .02]))
+            w = int(rng.choice([1, 13, 60, 1000]))
+            lines.append(">seq%d some text" % r)
+            lines += [s[a:a + w] for a in range(0, L, w)]
+            if rng.random() < 0.3:
+                lines.append("")
+        kind, k = case % 6, int(rng.integers(0, len(lines)))
+        if kind == 0:
+            del lines[k]
+        elif kind == 1:
+            lines.insert(k, lines[k])
+        elif kind == 2:
+            lines.insert(k, [">x y", "@x", "ACGT", "", ">"][int(rng.integers(0, 5))])
+        elif kind == 3 and lines[k]:
+            lines[k] = ">@;A"[int(rng.integers(0, 4))] + lines[k][1:]
+        text = "\n".join(lines) + "\n"
+        if kind == 4:
+            text = text[:int(rng.integers(0, len(text) + 1))]
+        for argv in (["seq", "-r", "-p", "-v", "-t", "dna"], ["fx2tab", "-n", "-l", "-g"]):
+            want = run_cli(oracle_cli, argv, stdin=text)
+            for mode in MODES:
+                got = run_cli(cli, argv + mode, stdin=text)
+                assert want[0] in (0, 255) and got[0] == want[0], (case, kind, mode, text, got[2])
+                if want[0] == 0:
+                    assert got[1] == want[1], (case, kind, mode, text)
+        n_ok += want[0] == 0
+        n_bad += want[0] != 0
+    assert n_ok >= 30, (n_ok, n_bad)
+
+
 @pytest.mark.parametrize("mode", MODES, ids=["gpu-text", "host-parse"])
 def test_seq_small_batches_and_qual_only(cli, oracle_cli, mode):
     # batches / text blocks of a few records: results must not depend on where the input is cut

@@ -376,3 +376,48 @@ def test_wrapped_fastq_capacity_errors(env):
     assert gpu_parse(env, text, W, True, seq_capacity=7)[0].status == capi.PARSE_ECAPACITY
     res, names, seq, qual, offs = gpu_parse(env, text, W, True, max_records=3, seq_capacity=8)
     assert res.status == capi.PARSE_OK and seq == b"ACGTACGA" and qual == b"IIIIIIII" and names == [b"a", b"b", b"c"]
+
+
+def test_wrapped_fastq_damaged_texts(env, tmp_path):
+    """Small wrapped texts with a line deleted, doubled, inserted or re-headed, or cut at any byte: the device parser
+    accepts exactly the texts the reader restated from the reference accepts, with the same records."""
+    capi = env["capi"]
+    rng = np.random.default_rng(77)
+    path = str(tmp_path / "d.fq")
+    n_ok = n_bad = 0
+    for case in range(1400):
+        crlf = bool(case & 1)
+        eol = b"\r\n" if crlf else b"\n"
+        text = wrapped_fastq(rng, int(rng.integers(1, 6)), crlf, blank=0.3)
+        lines = text.split(eol)
+        tail = lines.pop()                                   # b"" behind the last line end
+        assert tail == b""
+        kind = case % 7
+        k = int(rng.integers(0, len(lines)))
+        if kind == 0:
+            del lines[k]
+        elif kind == 1:
+            lines.insert(k, lines[k])
+        elif kind == 2:
+            lines.insert(k, [b"@x y", b"+", b"ACGT", b"", b"+@+@"][int(rng.integers(0, 5))])
+        elif kind == 3 and lines[k]:
+            lines[k] = [b"@", b"+", b"A"][int(rng.integers(0, 3))] + lines[k][1:]
+        text = eol.join(lines) + eol
+        if kind == 4:
+            text = text[:int(rng.integers(0, len(text) + 1))]
+        elif kind == 5:
+            text = text[:-len(eol)]                          # no line end behind the last line
+        open(path, "wb").write(text)
+        try:
+            want = oracle_records(env["ora"], path)
+        except ValueError:
+            want = None
+        res, names, seq, qual, offs = gpu_parse(env, text, capi.FASTQ_WRAPPED, True)
+        if want is None:
+            n_bad += 1
+            assert res.status == capi.PARSE_EFORMAT, (case, kind, text)
+        else:
+            n_ok += 1
+            assert res.status == capi.PARSE_OK and res.consumed == len(text), (case, kind, res.status, text)
+            assert records_of(names, seq, qual, offs) == want, (case, kind, text)
+    assert n_ok > 50 and n_bad > 50, (n_ok, n_bad)
