@@ -661,6 +661,28 @@ __device__ __forceinline__ Fixed2 fixed2_of(double v)
     return f;
 }
 
+// "%.2f" of 100 * sum / len without the double: the text the arithmetic above prints, whenever this returns true.
+// The reference prints float64(sum) / float64(len) * 100 (for GC content float64(g) / float64(len) +
+// float64(c) / float64(len), times 100): two to four roundings of 2^-53 relative each, so the value whose
+// hundredths are printed is x = 10000 * sum / len within 5e-16 * x <= 5e-12 (sum <= len).  The printed hundredths
+// are x rounded to an integer, and x lies at least 1 / (2 len) > 7e-6 (len < 65536) from the nearest k + 1/2
+// unless it IS k + 1/2 -- then the roundings of the doubles decide and this returns false.  So apart from exact
+// ties, rounding the exact quotient gives the same digits: one 32-bit division with remainder (estimate from a
+// float reciprocal of len, off by one at most, put right by the remainder).
+__device__ __forceinline__ bool fixed2_ratio_fast(uint32_t sum, uint32_t len, float rlen, Fixed2& f)
+{
+    const uint32_t N = sum * 10000u;                      // < 2^32: sum <= len < 65536
+    uint32_t q = (uint32_t)((float)N * rlen);             // 10000 at most: the estimate is within 0.01 of N / len
+    uint32_t r = N - q * len;
+    if ((int32_t)r < 0) { q--; r += len; }
+    else if (r >= len) { q++; r -= len; }
+    if (2u * r == len) return false;                      // a tie at the hundredths: the doubles decide
+    q += 2u * r > len ? 1u : 0u;
+    const uint32_t ip = q / 100u;
+    f.neg = false; f.kind = 0; f.ip = ip; f.fp = q - 100u * ip;
+    return true;
+}
+
 // characters of the text of f; with PUT also written to buf (at most 24)
 template <bool PUT>
 __device__ __forceinline__ uint32_t fixed2_text(const Fixed2& f, uint8_t* buf)
@@ -691,24 +713,64 @@ __device__ __forceinline__ uint32_t fixed2_text(const Fixed2& f, uint8_t* buf)
     return n + nd + 3;
 }
 
-__device__ __forceinline__ uint64_t tab_term_sum(const FormatTabArgs& a, const TabColumn& c, uint64_t r)
+// The counts of counting pass 0 for one record, loaded before anything uses them: the columns come one after the
+// other, and a load per column, each waited for, is a chain of memory latencies per record -- which is what the
+// row kernels spent their time on (a wavefront has 64 rows to do and little else to overlap).  Passes beyond the
+// first (more than 8 classes asked for) are read where they are used.
+typedef uint64_t CountRow __attribute__((ext_vector_type(8)));       // (a vector, not an array: it stays in registers)
+
+__device__ __forceinline__ CountRow load_count_row(const FormatTabArgs& a, uint64_t r)
+{
+    CountRow row = 0;
+    const uint64_t* p = a.counts[0];
+    const uint32_t nc = a.nclass[0];
+    if (p == nullptr) return row;
+    p += r * nc;
+    if (nc == 4 && (reinterpret_cast<uintptr_t>(a.counts[0]) & 15) == 0) {       // (the same for every lane)
+        const uint4 lo = *reinterpret_cast<const uint4*>(p), hi = *reinterpret_cast<const uint4*>(p + 2);
+        row.s0 = lo.x | ((uint64_t)lo.y << 32); row.s1 = lo.z | ((uint64_t)lo.w << 32);
+        row.s2 = hi.x | ((uint64_t)hi.y << 32); row.s3 = hi.z | ((uint64_t)hi.w << 32);
+    } else {
+        if (nc > 0) row.s0 = p[0];
+        if (nc > 1) row.s1 = p[1];
+        if (nc > 2) row.s2 = p[2];
+        if (nc > 3) row.s3 = p[3];
+        if (nc > 4) row.s4 = p[4];
+        if (nc > 5) row.s5 = p[5];
+        if (nc > 6) row.s6 = p[6];
+        if (nc > 7) row.s7 = p[7];
+    }
+    return row;
+}
+
+__device__ __forceinline__ uint64_t tab_count(const FormatTabArgs& a, const CountRow& row, uint64_t r, uint32_t term)
+{
+    const uint32_t pass = term >> 3, cls = term & 7;      // (the same for every lane)
+    if (pass != 0) return a.counts[pass][r * a.nclass[pass] + cls];
+    uint64_t v = row.s0;
+    v = cls == 1 ? row.s1 : v; v = cls == 2 ? row.s2 : v; v = cls == 3 ? row.s3 : v; v = cls == 4 ? row.s4 : v;
+    v = cls == 5 ? row.s5 : v; v = cls == 6 ? row.s6 : v; v = cls == 7 ? row.s7 : v;
+    return v;
+}
+
+__device__ __forceinline__ uint64_t tab_term_sum(const FormatTabArgs& a, const TabColumn& c, const CountRow& row, uint64_t r)
 {
     uint64_t sum = 0;
-    for (uint32_t k = 0; k < c.nterm; k++) {
-        const uint32_t pass = c.term[k] >> 3, cls = c.term[k] & 7;
-        sum += a.counts[pass][r * a.nclass[pass] + cls];
-    }
+    for (uint32_t k = 0; k < c.nterm; k++) sum += tab_count(a, row, r, c.term[k]);
     return sum;
 }
 
 // The numeric columns of record r ("\t<number>" each), as fx2tab.go:127-143 prints them: their length,
 // and with PUT their characters at buf.
 template <bool PUT>
-__device__ uint32_t tab_numbers(const FormatTabArgs& a, uint64_t r, uint64_t len, uint8_t* buf)
+__device__ uint32_t tab_numbers(const FormatTabArgs& a, const CountRow& row, uint64_t r, uint64_t len, uint8_t* buf)
 {
     uint32_t n = 0;
-    double gg = 0, cc = 0;
+    uint64_t g = 0, cn = 0;
     bool have_gc = false;
+    const bool small = len - 1 < 65535;                   // 1 <= len < 65536: fixed2_ratio_fast applies
+    const uint32_t len32 = (uint32_t)len;
+    const float rlen = small ? __builtin_amdgcn_rcpf((float)len32) : 0.0f;
     for (uint32_t ci = 0; ci < a.ncols; ci++) {
         const TabColumn& c = a.cols[ci];
         if (PUT) buf[n] = '\t';
@@ -719,29 +781,80 @@ __device__ uint32_t tab_numbers(const FormatTabArgs& a, uint64_t r, uint64_t len
             n += nd;
             continue;
         }
+        Fixed2 f;
         if (c.kind == TAB_CONTENT) {
-            const double v = len ? (double)tab_term_sum(a, c, r) / (double)len : 0.0;
-            n += fixed2_text<PUT>(fixed2_of(v * 100), buf + n);
+            const uint64_t sum = tab_term_sum(a, c, row, r);
+            if (!(small && sum <= len && fixed2_ratio_fast((uint32_t)sum, len32, rlen, f))) {
+                const double v = len ? (double)sum / (double)len : 0.0;
+                f = fixed2_of(v * 100);
+            }
+            n += fixed2_text<PUT>(f, buf + n);
             continue;
         }
         if (!have_gc) {
-            // two separate divisions, then the sum (fx2tab.go:128-133)
-            const uint32_t pg = c.term[0] >> 3, kg = c.term[0] & 7, pc = c.term[1] >> 3, kc = c.term[1] & 7;
-            gg = len ? (double)a.counts[pg][r * a.nclass[pg] + kg] / (double)len : 0.0;
-            cc = len ? (double)a.counts[pc][r * a.nclass[pc] + kc] / (double)len : 0.0;
+            g = tab_count(a, row, r, c.term[0]);
+            cn = tab_count(a, row, r, c.term[1]);
             have_gc = true;
         }
+        if (c.kind == TAB_GC && small && g + cn <= len && fixed2_ratio_fast((uint32_t)(g + cn), len32, rlen, f)) {
+            n += fixed2_text<PUT>(f, buf + n);
+            continue;
+        }
+        // two separate divisions, then the sum (fx2tab.go:128-133)
+        const double gg = len ? (double)g / (double)len : 0.0, cc = len ? (double)cn / (double)len : 0.0;
         if (c.kind == TAB_GC) n += fixed2_text<PUT>(fixed2_of((gg + cc) * 100), buf + n);
         else n += fixed2_text<PUT>(fixed2_of((gg - cc) / (gg + cc) * 100), buf + n);
     }
     return n;
 }
 
+// The length of the numeric columns when every percentage among them can be had from one integer division
+// (fixed2_ratio_fast: records of 1 to 65535 bases, no GC-skew column, no tie at the hundredths) -- `ok` says
+// whether that held; if not, the value returned means nothing.  Straight-line code but for the column kinds,
+// which are the same for every lane: a percentage q / 100 with q <= 10000 has 4 characters, 5 from 10.00, 6 at 100.00.
+__device__ __forceinline__ uint32_t tab_numbers_size_fast(const FormatTabArgs& a, const CountRow& row, uint64_t r, uint64_t len64,
+                                                          bool& ok)
+{
+    const uint32_t len = (uint32_t)len64;
+    const float rlen = __builtin_amdgcn_rcpf((float)len);
+    bool good = len64 - 1 < 65535;
+    uint32_t n = 0;
+    uint64_t gc = 0;
+    bool have_gc = false;
+    for (uint32_t ci = 0; ci < a.ncols; ci++) {
+        const TabColumn& c = a.cols[ci];
+        n++;
+        if (c.kind == TAB_LENGTH) {
+            n += 1u + (len >= 10u) + (len >= 100u) + (len >= 1000u) + (len >= 10000u);
+            continue;
+        }
+        if (c.kind == TAB_GC_SKEW) { good = false; continue; }
+        uint64_t sum;
+        if (c.kind == TAB_CONTENT) sum = tab_term_sum(a, c, row, r);
+        else {
+            if (!have_gc) { gc = tab_count(a, row, r, c.term[0]) + tab_count(a, row, r, c.term[1]); have_gc = true; }
+            sum = gc;
+        }
+        good = good && sum <= len64;
+        const uint32_t N = (uint32_t)sum * 10000u;
+        uint32_t q = (uint32_t)((float)N * rlen);
+        uint32_t rem = N - q * len;
+        const bool under = (int32_t)rem < 0, over = !under && rem >= len;
+        q = under ? q - 1 : (over ? q + 1 : q);
+        rem = under ? rem + len : (over ? rem - len : rem);
+        good = good && 2u * rem != len;
+        q += 2u * rem > len ? 1u : 0u;
+        n += 4u + (q >= 1000u) + (q >= 10000u);
+    }
+    ok = good;
+    return n;
+}
+
 // what follows the quality field of row r: the numeric columns, the alphabet column (fx2tab.go:145-147:
 // a tab and the byte values present, ascending) and the line end
-__device__ __forceinline__ void tab_row_tail(const FormatTabArgs& a, uint64_t r, uint64_t len, uint8_t* o)
+__device__ __forceinline__ void tab_row_tail(const FormatTabArgs& a, const CountRow& row, uint64_t r, uint64_t len, uint8_t* o)
 {
-    o += tab_numbers<true>(a, r, len, o);
+    o += tab_numbers<true>(a, row, r, len, o);
     if (a.letters) {
         *o++ = '\t';
         for (uint32_t i = 0; i < 8; i++) {
@@ -760,10 +873,13 @@ __global__ __launch_bounds__(FB) void k_tab_sizes(const FormatTabArgs a, uint64_
                                                   uint32_t* __restrict__ shown_name)
 {
     for (uint64_t r = (uint64_t)blockIdx.x * FB + threadIdx.x; r < a.nrec; r += (uint64_t)gridDim.x * FB) {
+        const CountRow row = load_count_row(a, r);
         const uint64_t len = a.offsets[r + 1] - a.offsets[r];
         uint32_t nl = a.name_len[r];
         if (a.only_id) nl = id_length(a.text + a.name_pos[r], nl);
-        const uint32_t nn = tab_numbers<false>(a, r, len, nullptr);
+        bool fast;
+        uint32_t nn = tab_numbers_size_fast(a, row, r, len, fast);
+        if (!fast) nn = tab_numbers<false>(a, row, r, len, nullptr);
         uint32_t na = 0;                                  // alphabet column: a tab and the letters present
         if (a.letters) {
             na = 1;
@@ -794,6 +910,7 @@ __global__ __launch_bounds__(FB) void k_tab_rows(const FormatTabArgs a, const ui
         if (blockIdx.x == 0 && threadIdx.x == 0) *n_direct = 1u;
         return;
     }
+    const bool print_seq = a.print_seq, print_qual = a.print_qual;
     uint8_t* stage = s_stage[wave];
     for (uint64_t step = (uint64_t)blockIdx.x * (FB / 64) + wave; step < nsteps; step += (uint64_t)gridDim.x * (FB / 64)) {
         const uint64_t r0 = step * R;
@@ -801,8 +918,10 @@ __global__ __launch_bounds__(FB) void k_tab_rows(const FormatTabArgs a, const ui
         // lane i holds the tables of record r0 + i
         uint64_t t_pos = 0, t_end = 0, t_s = 0, t_name = 0, t_len64 = 0;
         uint32_t t_nl = 0, t_len = 0;                     // t_len: for the copies (a printed field fits the stage)
+        CountRow t_row = 0;
         if (lane < n) {
             const uint64_t r = r0 + lane;
+            t_row = load_count_row(a, r);
             const uint64_t s = a.offsets[r], e = a.offsets[r + 1];
             t_pos = pos[r]; t_end = t_pos + size[r]; t_s = s; t_len64 = e - s; t_len = t_len64 > 0xffffffffull ? 0xffffffffu : (uint32_t)t_len64;
             t_nl = shown_name[r]; t_name = a.name_pos[r];
@@ -815,8 +934,8 @@ __global__ __launch_bounds__(FB) void k_tab_rows(const FormatTabArgs a, const ui
         }
         // (a row that fits the stage holds its bases and qualities: the record is shorter than the stage)
         if (lane < n) {
-            const uint32_t at = (uint32_t)(t_pos - a0) + t_nl + 1 + (a.print_seq ? t_len : 0) + 1 + (a.print_qual ? t_len : 0);
-            tab_row_tail(a, r0 + lane, t_len64, stage + at);
+            const uint32_t at = (uint32_t)(t_pos - a0) + t_nl + 1 + (print_seq ? t_len : 0) + 1 + (print_qual ? t_len : 0);
+            tab_row_tail(a, t_row, r0 + lane, t_len64, stage + at);
         }
         // the tabs by each record's own lane; the 16-byte pieces of names, bases and qualities of all rows dealt
         // over the 64 lanes, field by field (see write_step_flat)
@@ -824,14 +943,14 @@ __global__ __launch_bounds__(FB) void k_tab_rows(const FormatTabArgs a, const ui
         const uint32_t f_len = lane < n ? t_len : 0u, f_nl = lane < n ? t_nl : 0u;
         if (lane < n) {
             stage[op + t_nl] = '\t';
-            stage[op + t_nl + 1 + (a.print_seq ? t_len : 0u)] = '\t';
+            stage[op + t_nl + 1 + (print_seq ? t_len : 0u)] = '\t';
         }
         const uint64_t s0 = from_lane64(t_s, 0);
         const uint32_t s_rel = (uint32_t)(t_s - s0);
         const Div32 no_wrap(0);
 #pragma unroll 1
         for (int f = 0; f < 3; f++) {
-            if ((f == 1 && !a.print_seq) || (f == 2 && !a.print_qual)) continue;
+            if ((f == 1 && !print_seq) || (f == 2 && !print_qual)) continue;
             const uint32_t PF = wave_max32(((f == 0 ? f_nl : f_len) + 15) >> 4);
             if (PF == 0) continue;
             flat_copy_field<FMT_ROUNDS>(stage, lane, n, PF, false, no_wrap, [&](uint32_t r, uint32_t& L, uint32_t& at, const uint8_t*& src) {
@@ -839,7 +958,7 @@ __global__ __launch_bounds__(FB) void k_tab_rows(const FormatTabArgs a, const ui
                 const uint32_t nl_r = (uint32_t)__shfl((int)f_nl, (int)r), srel_r = (uint32_t)__shfl((int)s_rel, (int)r);
                 const uint64_t name_r = f == 0 ? from_lane64(t_name, r) : 0;
                 L = f == 0 ? nl_r : len_r;
-                at = op_r + (f == 0 ? 0u : nl_r + 1 + (f == 2 ? (a.print_seq ? len_r : 0u) + 1 : 0u));
+                at = op_r + (f == 0 ? 0u : nl_r + 1 + (f == 2 ? (print_seq ? len_r : 0u) + 1 : 0u));
                 src = f == 0 ? a.text + name_r : (f == 1 ? a.seq : a.qual) + s0 + srel_r;
             });
         }
@@ -904,7 +1023,7 @@ __global__ __launch_bounds__(FB) void k_tab_numbers(const FormatTabArgs a, const
     for (uint64_t r = (uint64_t)blockIdx.x * FB + threadIdx.x; r < a.nrec; r += (uint64_t)gridDim.x * FB) {
         if (!all_direct && !step_is_direct(r, R, a.nrec, pos, size)) continue;
         const uint64_t len = a.offsets[r + 1] - a.offsets[r];
-        tab_row_tail(a, r, len, out + pos[r] + shown_name[r] + 1 + (a.print_seq ? len : 0) + 1 + (a.print_qual ? len : 0));
+        tab_row_tail(a, load_count_row(a, r), r, len, out + pos[r] + shown_name[r] + 1 + (a.print_seq ? len : 0) + 1 + (a.print_qual ? len : 0));
     }
 }
 

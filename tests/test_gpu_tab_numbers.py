@@ -12,7 +12,8 @@ pytestmark = pytest.mark.gpu
 MAXLEN = 2048
 
 
-def test_every_count_and_length(oracle_lib):
+def check_rows(oracle_lib, lens, g, c):
+    """The device's rows for records of lengths `lens` with g G's and c C's against the oracle's."""
     import torch
     import seqkit_amd
     from seqkit_amd import capi
@@ -20,11 +21,6 @@ def test_every_count_and_length(oracle_lib):
     ctx = lib.init(0)
     dev = torch.device("cuda", 0)
     try:
-        lens = np.repeat(np.arange(MAXLEN + 1, dtype=np.uint64), np.arange(1, MAXLEN + 2))
-        first = np.cumsum(np.arange(1, MAXLEN + 2)) - np.arange(1, MAXLEN + 2)
-        g = (np.arange(len(lens), dtype=np.uint64) - np.repeat(first, np.arange(1, MAXLEN + 2)).astype(np.uint64))
-        assert g.max() == MAXLEN and bool((g <= lens).all())
-        c = (lens - g) // np.uint64(3)                      # some C besides the G: the sum of two quotients
         nrec = len(lens)
         offs = np.zeros(nrec + 1, np.uint64)
         np.cumsum(lens, out=offs[1:])
@@ -78,7 +74,34 @@ def test_every_count_and_length(oracle_lib):
             i = int(np.nonzero(got != ref)[0][0])
             raise AssertionError("first difference at byte %d: want %r got %r" %
                                  (i, want_text[max(0, i - 40):i + 20], got[max(0, i - 40):i + 20].tobytes()))
-        # the pairs the reference's documentation shows (doc/docs/usage.md: 41.87 etc. come from rounding twice)
-        assert b"\t50.00\t" in want_text and b"NaN" in want_text
+        return want_text
     finally:
         lib.skh_destroy(ctx)
+
+
+def test_every_count_and_length(oracle_lib):
+    lens = np.repeat(np.arange(MAXLEN + 1, dtype=np.uint64), np.arange(1, MAXLEN + 2))
+    first = np.cumsum(np.arange(1, MAXLEN + 2)) - np.arange(1, MAXLEN + 2)
+    g = (np.arange(len(lens), dtype=np.uint64) - np.repeat(first, np.arange(1, MAXLEN + 2)).astype(np.uint64))
+    assert g.max() == MAXLEN and bool((g <= lens).all())
+    c = (lens - g) // np.uint64(3)                      # some C besides the G: the sum of two quotients
+    want_text = check_rows(oracle_lib, lens, g, c)
+    # the pairs the reference's documentation shows (doc/docs/usage.md: 41.87 etc. come from rounding twice)
+    assert b"\t50.00\t" in want_text and b"NaN" in want_text
+
+
+def test_long_records_and_ties(oracle_lib):
+    """Percentages of records up to 65535 bases are printed from one integer division unless the hundredths are an
+    exact tie; longer records and ties take the float64 arithmetic.  Every count of lengths either side of that
+    limit and of lengths rich in ties (x.xx5 exactly: multiples of 2000, powers of two), and random pairs up to
+    2^20 bases."""
+    rng = np.random.default_rng(9)
+    full = [65535, 65536, 65534, 64000, 60000, 40000, 32768, 20000, 16384, 8000, 6000, 4000, 2000, 65537, 70000]
+    lens = np.concatenate([np.full(n + 1, n, np.uint64) for n in full])
+    g = np.concatenate([np.arange(n + 1, dtype=np.uint64) for n in full])
+    rl = rng.integers(1, 1 << 20, 400_000).astype(np.uint64)
+    rg = (rng.random(400_000) * (rl + np.uint64(1))).astype(np.uint64)
+    lens = np.concatenate([lens, rl]); g = np.concatenate([g, np.minimum(rg, rl)])
+    c = (lens - g) // np.uint64(3)
+    want_text = check_rows(oracle_lib, lens, g, c)
+    assert want_text.count(b".") == 3 * len(lens)

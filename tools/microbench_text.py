@@ -91,6 +91,13 @@ def run(kind):
     cptr = (C.c_void_p * 4)(counts.data_ptr(), None, None, None)
     ncl = (C.c_uint32 * 4)(4, 0, 0, 0)
 
+    def dense_names():
+        # experiment: what the rows would cost if the names stood one behind the other (a dense name plane) instead
+        # of 340 bytes apart in the text -- the spans point into the start of the text, the bytes are not the names
+        # (called behind the parse case, which writes the spans)
+        d_npos.copy_(torch.cumsum(d_nlen.to(torch.int64), 0) - d_nlen.to(torch.int64))
+        torch.cuda.synchronize()
+
     def format_tab():
         lib.check(lib.skh_format_tab_dev(ctx, d_text.data_ptr(), d_npos.data_ptr(), d_nlen.data_ptr(), d_seq.data_ptr(),
                                          d_qual.data_ptr(), d_offs.data_ptr(), nrec, cptr, ncl, C.byref(tf),
@@ -107,6 +114,8 @@ def run(kind):
     print("== %s: %d records x %d, text %.2f GB" % (kind, nrec, L, n / 1e9))
     with torch.cuda.stream(st):
         for name, (fn, nbytes) in cases.items():
+            if os.environ.get("DENSE_NAMES") and name.startswith("format fx2tab"):
+                dense_names()
             for _ in range(2): fn()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(st)
