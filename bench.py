@@ -540,40 +540,42 @@ def main():
     # library over RCCL (one rank per process; the id travels over torch.distributed's own channel)
     stats_d = torch.zeros(5, dtype=torch.int64, device=dev)
     stats_ms = b.time_ms(lambda: b.stats(seq, offs, nrec, total, stats_d), reps=10)
-    allreduce_us, comm_init_s = [], None
-    if args.no_collective:
-        stats = [int(x) for x in stats_d.cpu()]
-    else:
-        idbuf = torch.zeros(128, dtype=torch.uint8, device=dev)
-        if rank == 0:
-            raw = (C.c_uint8 * 128)()
-            lib.check(lib.skh_comm_unique_id(raw))
-            idbuf.copy_(torch.tensor(list(raw), dtype=torch.uint8))
-        if world > 1:
-            dist.broadcast(idbuf, src=0)
-        raw = (C.c_uint8 * 128)(*[int(x) for x in idbuf.cpu()])
-        comm = C.c_void_p()
-        t_init = time.perf_counter()
-        lib.check(lib.skh_comm_init_rank(ctx, raw, world, rank, C.byref(comm)))
-        comm_init_s = time.perf_counter() - t_init
-        dparts, streams = (C.c_void_p * 1)(stats_d.data_ptr()), (C.c_void_p * 1)(stream.cuda_stream)
-        for it in range(4):                                   # the first call sets up RCCL's channels
-            b.stats(seq, offs, nrec, total, stats_d)
-            barrier()
-            ta = time.perf_counter()
-            lib.check(lib.skh_stats_allreduce_dev(comm, dparts, streams))
-            torch.cuda.synchronize()
-            allreduce_us.append((time.perf_counter() - ta) * 1e6)
-        stats = [int(x) for x in stats_d.cpu()]
-        ok_stats = stats[:2] == [nrec * world, total * world] and stats[3:] == [L, L]
-        assert ok_stats, stats
-        lib.skh_comm_destroy(comm)
-    rccl = None
+    allreduce_us, comm_init_s, collective_error, rccl = [], None, None, None
+    stats = [int(x) for x in stats_d.cpu()]
     if not args.no_collective:
-        v = [C.c_int(0), C.c_int(0), C.c_int(0)]
-        lib.check(lib.skh_comm_rccl_version(C.byref(v[0]), C.byref(v[1]), C.byref(v[2])))
-        rccl = {"ncclGetVersion": v[0].value, "header_NCCL_VERSION_CODE": v[1].value,
-                "library": "the copy the process held (torch's)" if v[2].value else "opened by libseqkit_hip.so"}
+        # (a failure here is reported in the line, not allowed to take the line with it: the timed steps are done)
+        try:
+            idbuf = torch.zeros(128, dtype=torch.uint8, device=dev)
+            if rank == 0:
+                raw = (C.c_uint8 * 128)()
+                lib.check(lib.skh_comm_unique_id(raw))
+                idbuf.copy_(torch.tensor(list(raw), dtype=torch.uint8))
+            if world > 1:
+                dist.broadcast(idbuf, src=0)
+            raw = (C.c_uint8 * 128)(*[int(x) for x in idbuf.cpu()])
+            comm = C.c_void_p()
+            t_init = time.perf_counter()
+            lib.check(lib.skh_comm_init_rank(ctx, raw, world, rank, C.byref(comm)))
+            comm_init_s = time.perf_counter() - t_init
+            dparts, streams = (C.c_void_p * 1)(stats_d.data_ptr()), (C.c_void_p * 1)(stream.cuda_stream)
+            for it in range(4):                                   # the first call sets up RCCL's channels
+                b.stats(seq, offs, nrec, total, stats_d)
+                barrier()
+                ta = time.perf_counter()
+                lib.check(lib.skh_stats_allreduce_dev(comm, dparts, streams))
+                torch.cuda.synchronize()
+                allreduce_us.append((time.perf_counter() - ta) * 1e6)
+            stats = [int(x) for x in stats_d.cpu()]
+            if not (stats[:2] == [nrec * world, total * world] and stats[3:] == [L, L]):
+                raise RuntimeError("all-reduced totals are wrong: %r" % (stats,))
+            lib.skh_comm_destroy(comm)
+            v = [C.c_int(0), C.c_int(0), C.c_int(0)]
+            lib.check(lib.skh_comm_rccl_version(C.byref(v[0]), C.byref(v[1]), C.byref(v[2])))
+            rccl = {"ncclGetVersion": v[0].value, "header_NCCL_VERSION_CODE": v[1].value,
+                    "library": "the copy the process held (torch's)" if v[2].value else "opened by libseqkit_hip.so"}
+        except Exception as exc:                                  # noqa: BLE001 -- whatever it is, it goes into the line
+            collective_error = "%s: %s" % (type(exc).__name__, exc)
+            print("[bench] rank %d: collective leg failed: %s" % (rank, collective_error), file=sys.stderr, flush=True)
 
     # the same reverse-complement with one plane (skh_revcomp_inplace_dev), outside the timed steps
     work = seq.clone()
@@ -602,7 +604,11 @@ def main():
         if world > 1:                                    # every GPU needs the room; the e2e leg (N = 1) needs the batch
             del seq_out, qual_out, counts
             torch.cuda.empty_cache()
-        configs = other_configs(b, rank, world, host_xfer=args.rehearse)
+        try:
+            configs = other_configs(b, rank, world, host_xfer=args.rehearse)
+        except Exception as exc:                                  # noqa: BLE001 -- reported, the headline figure stands
+            configs = {"error": "%s: %s" % (type(exc).__name__, exc)}
+            print("[bench] rank %d: configs leg failed: %s" % (rank, configs["error"]), file=sys.stderr, flush=True)
         seq, qual = keep
 
     if rank == 0:
@@ -645,7 +651,8 @@ def main():
             "stats": {"totals": stats, "collective": "skh_stats_allreduce_dev: RCCL all-reduce of 5 x int64 (sum x3, min, max) "
                                                      "inside libseqkit_hip.so, %d rank(s)" % world,
                       "allreduce_us": [round(x, 1) for x in allreduce_us],
-                      "comm_init_s": None if comm_init_s is None else round(comm_init_s, 3), "rccl": rccl},
+                      "comm_init_s": None if comm_init_s is None else round(comm_init_s, 3), "rccl": rccl,
+                      "error": collective_error},
             "verified": ok,
         }
         if sustained is not None:
@@ -653,9 +660,12 @@ def main():
         if configs is not None:
             out["configs"] = configs
         if args.cpu_seconds > 0 and world == 1:
-            single, multi = cpu_baseline(args.cpu_seconds, L, b.lut, b.cls)
-            out["cpu_baseline"] = single
-            out["cpu_baseline_all_cores"] = multi
+            try:
+                single, multi = cpu_baseline(args.cpu_seconds, L, b.lut, b.cls)
+                out["cpu_baseline"] = single
+                out["cpu_baseline_all_cores"] = multi
+            except Exception as exc:                              # noqa: BLE001
+                out["cpu_baseline"] = {"value": None, "error": "%s: %s" % (type(exc).__name__, exc)}
         if not args.no_e2e and world == 1:
             torch.cuda.synchronize()
             try:
