@@ -389,7 +389,7 @@ __global__ __launch_bounds__(PB) void k_line_table(const uint8_t* __restrict__ t
                     const uint64_t t0 = (T0 + w_of[j]) * TILE;
                     e_here = nl_entry64(ent_here[j], t0);
                     e_before = k_of[j] ? nl_entry64(ent_before[j], t0) : s_before[w_of[j]];
-                    nlpos[i] = e_here;
+                    if (i + 1 == nlines) nlpos[i] = e_here;      // (only the last line's newline is ever looked up again)
                 } else {
                     e_before = s_before[0];                  // (T0 >= ntile here: every slot holds the text's last newline)
                 }
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(PB) void k_line_table(const uint8_t* __restrict__ t
                 if (bad && i < err) err = i;
                 line_start[i] = ls;
                 line_len[i] = len;
-                line_head[i] = raw_first ? c : (head ? 1 : 0);     // (raw_first: the line's first byte, for the wrapped-FASTQ passes)
+                if (!FASTQ) line_head[i] = raw_first ? c : (head ? 1 : 0);     // (raw_first: the line's first byte, for the wrapped-FASTQ passes)
             }
         }
     }
@@ -465,7 +465,7 @@ __device__ __forceinline__ LineSum line_item(const uint32_t* __restrict__ line_l
 {
     LineSum v{0, 0};
     if (i < nlines) {
-        const bool head = line_head[i] != 0;
+        const bool head = FASTQ ? (i & 3) == 0 : line_head[i] != 0;      // (four-line FASTQ: every fourth line, no table)
         v.heads = head ? 1u : 0u;
         if (FASTQ) v.bytes = (i & 3) == 1 ? line_len[i] : 0;
         else v.bytes = head ? 0 : line_len[i];
@@ -482,11 +482,12 @@ __device__ __forceinline__ void line_items(const uint32_t* __restrict__ line_len
     static_assert(SCAN_ITEMS == 8, "two 16-byte loads of lengths, one 8-byte load of flags");
     if (base + SCAN_ITEMS <= nlines) {
         const uint4 l0 = *reinterpret_cast<const uint4*>(line_len + base), l1 = *reinterpret_cast<const uint4*>(line_len + base + 4);
-        const uint2 hd = *reinterpret_cast<const uint2*>(line_head + base);
+        uint2 hd = make_uint2(0, 0);
+        if (!FASTQ) hd = *reinterpret_cast<const uint2*>(line_head + base);
         const uint32_t l[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            const bool head = (((k < 4 ? hd.x : hd.y) >> (8 * (k & 3))) & 0xffu) != 0;
+            const bool head = FASTQ ? (k & 3) == 0 : (((k < 4 ? hd.x : hd.y) >> (8 * (k & 3))) & 0xffu) != 0;
             len[k] = l[k];
             v[k].heads = head ? 1u : 0u;
             if (FASTQ) v[k].bytes = (k & 3) == 1 ? l[k] : 0;       // base is a multiple of 4
@@ -638,15 +639,18 @@ __global__ __launch_bounds__(PB) void k_line_scan(const uint32_t* __restrict__ l
         for (int k = 0; k < SCAN_ITEMS; k += 2)
             *reinterpret_cast<uint4*>(line_dst + base + k) =
                 make_uint4((uint32_t)d[k], (uint32_t)(d[k] >> 32), (uint32_t)d[k + 1], (uint32_t)(d[k + 1] >> 32));
+        if (!FASTQ) {                                     // (four-line FASTQ: line i belongs to record i / 4, nobody asks)
 #pragma unroll
-        for (int k = 0; k < SCAN_ITEMS; k += 4)
-            *reinterpret_cast<uint4*>(line_rank + base + k) = make_uint4(r[k], r[k + 1], r[k + 2], r[k + 3]);
+            for (int k = 0; k < SCAN_ITEMS; k += 4)
+                *reinterpret_cast<uint4*>(line_rank + base + k) = make_uint4(r[k], r[k + 1], r[k + 2], r[k + 3]);
+        }
         return;
     }
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; k++) {
         if (base + k < nlines) {
-            line_dst[base + k] = rb; line_rank[base + k] = rh;
+            line_dst[base + k] = rb;
+            if (!FASTQ) line_rank[base + k] = rh;
             if (v[k].heads) {
                 if (rh < nrec_cap) { offsets[rh] = rb; name_pos[rh] = line_start[base + k] + 1; name_len[rh] = len[k] - 1; }
             } else if (!FASTQ && rh == 0 && len[k] != 0) {
