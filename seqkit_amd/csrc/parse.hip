@@ -278,6 +278,8 @@ struct ParseState {            // device scratch shared by the passes of one cal
     LineSum total;             // totals of the line scan
     uint64_t nrec, seq_bytes, consumed;    // the decision
     uint64_t nrec_cap;                     // complete records at most (known before the line scan), capped at the tables' size
+    uint64_t first_head, last_head;        // FASTA: the first and the last head line (~0 = none), noted by the line scan
+    uint64_t copy_lo, copy_hi;             // FASTA: the sequence lines i of the block's records are those with copy_lo < i < copy_hi
 };
 
 __global__ void k_parse_init(ParseState* st, uint64_t n, int final, const uint8_t* __restrict__ text,
@@ -295,6 +297,8 @@ __global__ void k_parse_init(ParseState* st, uint64_t n, int final, const uint8_
     st->n_long = 0;
     st->total.bytes = 0;
     st->total.heads = 0;
+    st->first_head = ~0ull; st->last_head = ~0ull;
+    st->copy_lo = ~0ull; st->copy_hi = 0;
 }
 
 // Line i: its start, its length without the trailing '\r's, and its first byte (0 if empty).
@@ -334,7 +338,8 @@ __global__ __launch_bounds__(PB) void k_line_table(const uint8_t* __restrict__ t
                                                    const uint64_t* __restrict__ tile_base, const uint64_t* __restrict__ tile_last,
                                                    ParseState* st, uint64_t* __restrict__ nlpos,
                                                    uint64_t* __restrict__ line_start, uint32_t* __restrict__ line_len,
-                                                   uint8_t* __restrict__ line_head, int raw_first)
+                                                   uint8_t* __restrict__ line_head, int raw_first,
+                                                   uint64_t max_records, uint64_t* __restrict__ name_pos, uint32_t* __restrict__ name_len)
 {
     __shared__ uint64_t s_base[LT_TILES + 1], s_before[LT_TILES];
     const uint64_t nlines = st->nlines, n_nl = st->n_nl;
@@ -416,6 +421,9 @@ __global__ __launch_bounds__(PB) void k_line_table(const uint8_t* __restrict__ t
                 line_start[i] = ls;
                 line_len[i] = len;
                 if (!FASTQ) line_head[i] = raw_first ? c : (head ? 1 : 0);     // (raw_first: the line's first byte, for the wrapped-FASTQ passes)
+                // four-line FASTQ: line 4 r is the head of record r, whatever comes of the block (entries beyond the
+                // records the block ends up with are never looked at)
+                if (FASTQ && head && (i >> 2) < max_records) { name_pos[i >> 2] = ls + 1; name_len[i >> 2] = len - 1; }
             }
         }
     }
@@ -502,6 +510,27 @@ __device__ __forceinline__ void line_items(const uint32_t* __restrict__ line_len
     }
 }
 
+// Four-line FASTQ: the items of the scan are RECORDS (lines 4 r .. 4 r + 3, their lengths one 16-byte load):
+// bytes = the length of the sequence line, heads = 1.  `base` counts records.  With `check`, a quality line that
+// is not as long as its sequence line is reported (complete records only).
+__device__ __forceinline__ void record_items(const uint32_t* __restrict__ line_len, uint64_t base, uint64_t nlines, ParseState* st,
+                                             bool check, LineSum* v)
+{
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) {
+        const uint64_t i0 = 4 * (base + k);
+        v[k] = LineSum{0, 0};
+        if (i0 + 4 <= nlines) {
+            const uint4 l = *reinterpret_cast<const uint4*>(line_len + i0);
+            v[k].bytes = l.y; v[k].heads = 1;
+            if (check && l.w != l.y) atomicMin(&st->err_line, (unsigned long long)(i0 + 3));
+        } else if (i0 < nlines) {                         // the block ends inside the record
+            v[k].heads = 1;
+            if (i0 + 1 < nlines) v[k].bytes = line_len[i0 + 1];
+        }
+    }
+}
+
 template <bool FASTQ>
 __global__ __launch_bounds__(PB) void k_line_partials(const uint32_t* __restrict__ line_len,
                                                       const uint8_t* __restrict__ line_head, ParseState* st,
@@ -514,14 +543,10 @@ __global__ __launch_bounds__(PB) void k_line_partials(const uint32_t* __restrict
     uint64_t b = 0; uint32_t h = 0;
     LineSum v[SCAN_ITEMS];
     uint32_t len[SCAN_ITEMS];
-    line_items<FASTQ>(line_len, line_head, base, nlines, v, len);
+    if (FASTQ) record_items(line_len, base, nlines, st, true, v);      // (a quality line must be as long as its sequence line)
+    else line_items<FASTQ>(line_len, line_head, base, nlines, v, len);
 #pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; k++) {
-        b += v[k].bytes; h += v[k].heads;
-        // FASTQ: a quality line must be as long as its sequence line (two lines up, held by the same thread)
-        if (FASTQ && (k & 3) == 3 && base + k < nlines && len[k] != len[k - 2])
-            atomicMin(&st->err_line, (unsigned long long)(base + k));
-    }
+    for (int k = 0; k < SCAN_ITEMS; k++) { b += v[k].bytes; h += v[k].heads; }
     for (int d = 1; d < 64; d <<= 1) { b += __shfl_xor(b, d); h += __shfl_xor(h, d); }
     if ((threadIdx.x & 63) == 0) { s_b[threadIdx.x >> 6] = b; s_h[threadIdx.x >> 6] = h; }
     __syncthreads();
@@ -597,7 +622,7 @@ template <bool FASTQ>
 __global__ __launch_bounds__(PB) void k_line_scan(const uint32_t* __restrict__ line_len,
                                                   const uint8_t* __restrict__ line_head, ParseState* st,
                                                   const LineSum* __restrict__ part, uint64_t* __restrict__ line_dst,
-                                                  uint32_t* __restrict__ line_rank, const uint64_t* __restrict__ line_start,
+                                                  const uint64_t* __restrict__ line_start,
                                                   uint64_t max_records, uint64_t* __restrict__ offsets,
                                                   uint64_t* __restrict__ name_pos, uint32_t* __restrict__ name_len)
 {
@@ -608,7 +633,8 @@ __global__ __launch_bounds__(PB) void k_line_scan(const uint32_t* __restrict__ l
     LineSum v[SCAN_ITEMS];
     uint32_t len[SCAN_ITEMS];
     uint64_t b = 0; uint32_t h = 0;
-    line_items<FASTQ>(line_len, line_head, base, nlines, v, len);
+    if (FASTQ) record_items(line_len, base, nlines, st, false, v);
+    else line_items<FASTQ>(line_len, line_head, base, nlines, v, len);
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; k++) { b += v[k].bytes; h += v[k].heads; }
     // inclusive scan of the per-thread sums across the wavefront, then across wavefronts
@@ -623,6 +649,17 @@ __global__ __launch_bounds__(PB) void k_line_scan(const uint32_t* __restrict__ l
     uint64_t rb = part[blockIdx.x].bytes + ib - b; uint32_t rh = part[blockIdx.x].heads + ih - h;
     for (uint32_t w = 0; w < wave; w++) { rb += s_b[w]; rh += s_h[w]; }
     const uint64_t nrec_cap = st->nrec_cap;
+    const uint32_t nheads = st->total.heads;              // (from the scan of the workgroup sums)
+    if (FASTQ) {
+        // record base + k starts at the sum before it; one entry beyond the records the block can end up with, for
+        // the decision to read (the names were written with the line table)
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; k++) {
+            if (v[k].heads && base + k <= nrec_cap && nrec_cap != 0) offsets[base + k] = rb;
+            rb += v[k].bytes;
+        }
+        return;
+    }
     if (base + SCAN_ITEMS <= nlines) {                    // 16-byte stores
         uint64_t d[SCAN_ITEMS]; uint32_t r[SCAN_ITEMS];
 #pragma unroll
@@ -631,6 +668,8 @@ __global__ __launch_bounds__(PB) void k_line_scan(const uint32_t* __restrict__ l
         for (int k = 0; k < SCAN_ITEMS; k++) {
             if (v[k].heads) {
                 if (r[k] < nrec_cap) { offsets[r[k]] = d[k]; name_pos[r[k]] = line_start[base + k] + 1; name_len[r[k]] = len[k] - 1; }
+                if (r[k] == 0) st->first_head = base + k;             // (one writer each)
+                if (r[k] + 1 == nheads) st->last_head = base + k;
             } else if (!FASTQ && r[k] == 0 && len[k] != 0) {
                 atomicMin(&st->err_line, (unsigned long long)(base + k));
             }
@@ -639,20 +678,16 @@ __global__ __launch_bounds__(PB) void k_line_scan(const uint32_t* __restrict__ l
         for (int k = 0; k < SCAN_ITEMS; k += 2)
             *reinterpret_cast<uint4*>(line_dst + base + k) =
                 make_uint4((uint32_t)d[k], (uint32_t)(d[k] >> 32), (uint32_t)d[k + 1], (uint32_t)(d[k + 1] >> 32));
-        if (!FASTQ) {                                     // (four-line FASTQ: line i belongs to record i / 4, nobody asks)
-#pragma unroll
-            for (int k = 0; k < SCAN_ITEMS; k += 4)
-                *reinterpret_cast<uint4*>(line_rank + base + k) = make_uint4(r[k], r[k + 1], r[k + 2], r[k + 3]);
-        }
         return;
     }
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; k++) {
         if (base + k < nlines) {
             line_dst[base + k] = rb;
-            if (!FASTQ) line_rank[base + k] = rh;
             if (v[k].heads) {
                 if (rh < nrec_cap) { offsets[rh] = rb; name_pos[rh] = line_start[base + k] + 1; name_len[rh] = len[k] - 1; }
+                if (rh == 0) st->first_head = base + k;
+                if (rh + 1 == nheads) st->last_head = base + k;
             } else if (!FASTQ && rh == 0 && len[k] != 0) {
                 atomicMin(&st->err_line, (unsigned long long)(base + k));
             }
@@ -676,7 +711,7 @@ __device__ __forceinline__ uint64_t start_of_line(uint64_t k, uint64_t nlines, u
 template <bool FASTQ>
 __global__ void k_parse_decide(ParseState* st, uint64_t n, int final, uint64_t max_lines,
                                const uint64_t* __restrict__ nlpos, const uint64_t* __restrict__ line_start,
-                               const uint64_t* __restrict__ line_dst, const uint32_t* __restrict__ line_rank,
+                               const uint64_t* __restrict__ line_dst,
                                uint64_t max_records, uint64_t* __restrict__ offsets)
 {
     const uint64_t L = st->nlines, n_nl = st->n_nl;
@@ -686,16 +721,15 @@ __global__ void k_parse_decide(ParseState* st, uint64_t n, int final, uint64_t m
         status = PARSE_ECAPACITY;                        // the line tables were too small for this text
     } else if (!FASTQ) {
         const uint64_t H = st->total.heads;
+        st->copy_lo = st->first_head;                     // (no head line: ~0, no line is copied)
         if (final) {
             nrec = H; seq_bytes = st->total.bytes; consumed = n;
+            st->copy_hi = L;
         } else if (H > 1) {
-            // the record of the last head line may continue in the next block: stop before it.
-            // line_rank (heads before a line) is non-decreasing; the last head line is the last
-            // line with rank H-1
-            uint64_t lo = 0, hi = L;                      // first line with rank >= H
-            while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (line_rank[mid] >= H) hi = mid; else lo = mid + 1; }
-            const uint64_t last_head = lo - 1;
+            // the record of the last head line may continue in the next block: stop before it
+            const uint64_t last_head = st->last_head;
             nrec = H - 1; seq_bytes = line_dst[last_head]; consumed = line_start[last_head];
+            st->copy_hi = last_head;
         }
     } else {
         const unsigned long long err = st->err_line, fbh = st->first_blank_head;
@@ -711,7 +745,10 @@ __global__ void k_parse_decide(ParseState* st, uint64_t n, int final, uint64_t m
         if (bad) { status = PARSE_EFORMAT; st->err_line = bad_line; nrec = 0; }
         else {
             st->err_line = ~0ull;
-            seq_bytes = nrec * 4 < L ? line_dst[nrec * 4] : st->total.bytes;
+            // where record nrec would start: the scan left it in offsets[nrec] (nothing was written for a block with
+            // more records than the tables hold)
+            const uint64_t R = (L + 3) / 4;
+            seq_bytes = (nrec == 0 || nrec > max_records) ? 0 : (nrec < R ? offsets[nrec] : st->total.bytes);
             consumed = final ? n : start_of_line(nrec * 4, L, n_nl, n, line_start, nlpos);
         }
     }
@@ -787,7 +824,7 @@ __global__ __launch_bounds__(PB) void k_parse_copy(const ParseState* st, uint64_
                                                    const uint32_t* __restrict__ line_len,
                                                    const uint8_t* __restrict__ line_head,
                                                    const uint64_t* __restrict__ line_dst,
-                                                   const uint32_t* __restrict__ line_rank,
+                                                   const uint64_t* __restrict__ offsets,
                                                    uint8_t* __restrict__ seq, uint8_t* __restrict__ qual)
 {
     constexpr uint32_t G = 8, GROUPS = 64 / G, NPLANE = FASTQ ? 2 : 1;
@@ -795,6 +832,7 @@ __global__ __launch_bounds__(PB) void k_parse_copy(const ParseState* st, uint64_
     const uint32_t lane = threadIdx.x & 63, j = lane & (G - 1), grp = lane / G;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint64_t nrec = st->nrec, nlines = st->nlines, seq_bytes = st->seq_bytes;
+    const uint64_t copy_lo = st->copy_lo, copy_hi = st->copy_hi;
     if (st->status != PARSE_OK || nrec > max_records || seq_bytes > seq_capacity) return;
     const uint64_t nwork = FASTQ ? 2 * ((nlines + 3) / 4) : nlines;
     // work items per step, from the mean number of bytes an item brings
@@ -819,10 +857,9 @@ __global__ __launch_bounds__(PB) void k_parse_copy(const ParseState* st, uint64_
             if (i < nlines) {
                 if (FASTQ) {
                     const uint32_t role = (uint32_t)(i & 3);
-                    if ((i >> 2) < nrec) { valid = true; t_dst = line_dst[role == 1 ? i : i - 2]; t_q = role == 3; }
+                    if ((i >> 2) < nrec) { valid = true; t_dst = offsets[i >> 2]; t_q = role == 3; }
                 } else {
-                    const uint32_t rank = line_rank[i];
-                    if (!(line_head[i] || rank == 0 || rank - 1 >= nrec)) { valid = true; t_dst = line_dst[i]; }
+                    if (i > copy_lo && i < copy_hi && !line_head[i]) { valid = true; t_dst = line_dst[i]; }
                 }
                 if (valid) { t_len = line_len[i]; t_start = line_start[i]; }
             }
@@ -924,7 +961,7 @@ __global__ __launch_bounds__(PB) void k_parse_copy_long(const ParseState* st, ui
                                                         const uint32_t* __restrict__ line_len,
                                                         const uint8_t* __restrict__ line_head,
                                                         const uint64_t* __restrict__ line_dst,
-                                                        const uint32_t* __restrict__ line_rank,
+                                                        const uint64_t* __restrict__ offsets,
                                                         uint8_t* __restrict__ seq, uint8_t* __restrict__ qual)
 {
     const uint64_t nrec = st->nrec, nlines = st->nlines;
@@ -953,10 +990,9 @@ __global__ __launch_bounds__(PB) void k_parse_copy_long(const ParseState* st, ui
                 const uint32_t role = (uint32_t)(i & 3);
                 if ((role != 1 && role != 3) || (i >> 2) >= nrec) continue;
                 dst_plane = role == 1 ? seq : qual;
-                dst = line_dst[role == 1 ? i : i - 2];
+                dst = offsets[i >> 2];
             } else {
-                const uint32_t rank = line_rank[i];
-                if (line_head[i] || rank == 0 || rank - 1 >= nrec) continue;
+                if (!(i > st->copy_lo && i < st->copy_hi) || line_head[i]) continue;
                 dst_plane = seq;
                 dst = line_dst[i];
             }
@@ -1222,7 +1258,7 @@ static inline uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a
 
 // Workspace layout for `max_lines` lines and `text_bytes` of text (all sections 256-byte aligned).
 struct ParseLayout {
-    uint64_t state, tile_count, tile_base, tile_last, nl_tile, nlpos, line_start, line_len, line_head, line_dst, line_rank, part, end;
+    uint64_t state, tile_count, tile_base, tile_last, nl_tile, nlpos, line_start, line_len, line_head, line_dst, part, end;
     ParseLayout(uint64_t text_bytes, uint64_t max_lines)
     {
         const uint64_t ntile = (text_bytes + TILE - 1) / TILE + 1;
@@ -1238,7 +1274,6 @@ struct ParseLayout {
         line_len = o; o = align_up(o + max_lines * 4, 256);
         line_head = o; o = align_up(o + max_lines, 256);
         line_dst = o; o = align_up(o + max_lines * 8, 256);
-        line_rank = o; o = align_up(o + max_lines * 4, 256);
         part = o; o = align_up(o + npart * sizeof(LineSum), 256);
         end = o;
     }
@@ -1265,7 +1300,6 @@ static hipError_t launch_parse_t(const uint8_t* text, uint64_t n, int final, uin
     uint32_t* line_len = reinterpret_cast<uint32_t*>(ws + lay.line_len);
     uint8_t* line_head = ws + lay.line_head;
     uint64_t* line_dst = reinterpret_cast<uint64_t*>(ws + lay.line_dst);
-    uint32_t* line_rank = reinterpret_cast<uint32_t*>(ws + lay.line_rank);
     LineSum* part = reinterpret_cast<LineSum*>(ws + lay.part);
 
     const uint64_t ntile = (n + TILE - 1) / TILE;
@@ -1275,24 +1309,26 @@ static hipError_t launch_parse_t(const uint8_t* text, uint64_t n, int final, uin
     const uint64_t lines_cap = max_lines < n + 1 ? max_lines : n + 1;
     auto capped = [](uint64_t blocks) { return (uint32_t)(blocks < 1 ? 1 : (blocks > 16384 ? 16384 : blocks)); };
     const uint32_t gl = capped((lines_cap + PB - 1) / PB);            // grid-stride kernels
-    const uint64_t npart = (lines_cap + SCAN_TILE - 1) / SCAN_TILE ? (lines_cap + SCAN_TILE - 1) / SCAN_TILE : 1;
+    // the items of the scan: lines, for four-line FASTQ records
+    const uint64_t items_cap = FASTQ ? (lines_cap + 3) / 4 : lines_cap;
+    const uint64_t npart = (items_cap + SCAN_TILE - 1) / SCAN_TILE ? (items_cap + SCAN_TILE - 1) / SCAN_TILE : 1;
     const uint32_t gc = capped((lines_cap * 8 + PB - 1) / PB);
 
     hipLaunchKernelGGL(k_nl_index, dim3(gt), dim3(PB), 0, s, text, n, tile_count, tile_last, nl_tile);
     hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, tile_count, ntile, tile_base, &st->n_nl);
     hipLaunchKernelGGL(k_parse_init, dim3(1), dim3(1), 0, s, st, n, final, text, max_lines);
     hipLaunchKernelGGL((k_line_table<FASTQ>), dim3(gl < 2048 ? gl : 2048), dim3(PB), 0, s, text, n, ntile, nl_tile, tile_count, tile_base,
-                       tile_last, st, nlpos, line_start, line_len, line_head, 0);
+                       tile_last, st, nlpos, line_start, line_len, line_head, 0, max_records, name_pos, name_len);
     hipLaunchKernelGGL((k_line_partials<FASTQ>), dim3((uint32_t)npart), dim3(PB), 0, s, line_len, line_head, st, part);
     hipLaunchKernelGGL((k_scan_partials<FASTQ>), dim3(1), dim3(1024), 0, s, part, npart, st, final, max_records);
-    hipLaunchKernelGGL((k_line_scan<FASTQ>), dim3((uint32_t)npart), dim3(PB), 0, s, line_len, line_head, st, part, line_dst, line_rank,
+    hipLaunchKernelGGL((k_line_scan<FASTQ>), dim3((uint32_t)npart), dim3(PB), 0, s, line_len, line_head, st, part, line_dst,
                        line_start, max_records, offsets, name_pos, name_len);
-    hipLaunchKernelGGL((k_parse_decide<FASTQ>), dim3(1), dim3(1), 0, s, st, n, final, max_lines, nlpos, line_start, line_dst, line_rank,
+    hipLaunchKernelGGL((k_parse_decide<FASTQ>), dim3(1), dim3(1), 0, s, st, n, final, max_lines, nlpos, line_start, line_dst,
                        max_records, offsets);
     hipLaunchKernelGGL((k_parse_copy<FASTQ>), dim3(gc), dim3(PB), 0, s, st, max_records, seq_capacity, text, line_start,
-                       line_len, line_head, line_dst, line_rank, seq, qual);
+                       line_len, line_head, line_dst, offsets, seq, qual);
     hipLaunchKernelGGL((k_parse_copy_long<FASTQ>), dim3(1024), dim3(PB), 0, s, st, max_records, seq_capacity, text, n,
-                       line_start, line_len, line_head, line_dst, line_rank, seq, qual);
+                       line_start, line_len, line_head, line_dst, offsets, seq, qual);
     hipLaunchKernelGGL(k_parse_finish, dim3(1), dim3(1), 0, s, st, max_records, seq_capacity, res);
     return hipGetLastError();
 }
@@ -1391,7 +1427,7 @@ hipError_t launch_parse_wrapped(const uint8_t* text, uint64_t n, int final, uint
     hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, tile_count, ntile, tile_base, &st->n_nl);
     hipLaunchKernelGGL(k_parse_init, dim3(1), dim3(1), 0, s, st, n, final, text, max_lines);
     hipLaunchKernelGGL((k_line_table<false>), dim3(gl < 2048 ? gl : 2048), dim3(PB), 0, s, text, n, ntile, nl_tile, tile_count, tile_base,
-                       tile_last, st, nlpos, line_start, line_len, line_first, 1);
+                       tile_last, st, nlpos, line_start, line_len, line_first, 1, 0, nullptr, nullptr);
     uint64_t* sums[3] = {cP, cPlus, cNb};
     for (int kind = 0; kind < 3; kind++) {
         hipLaunchKernelGGL(k_wq_flags, dim3(gw), dim3(WQ_B), 0, s, st, line_len, line_first, kind, cap, tmp);
