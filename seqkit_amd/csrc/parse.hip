@@ -200,67 +200,80 @@ __global__ __launch_bounds__(PB) void k_nl_index(const uint8_t* __restrict__ tex
     if (threadIdx.x == 0) tile_count[blockIdx.x] = count;
 }
 
-// exclusive scan of ntile uint32 counts into uint64 bases by ONE workgroup; total -> *n_out.
-// 16384 counts per round: every thread takes sixteen consecutive ones (four 16-byte loads; the workgroup's loads of
-// a round are one contiguous 64 KiB), wavefront scans by cross-lane reads, the 16 wavefront totals through LDS.
-// (One workgroup has the bandwidth of one compute unit: rounds are few and wide so that its latency is paid
-// seldom -- 4096 counts per round took 0.060 ms on 83 K tiles.)
-__global__ __launch_bounds__(1024) void k_scan_tiles(const uint32_t* __restrict__ cnt, uint64_t ntile,
-                                                     uint64_t* __restrict__ base, uint64_t* __restrict__ n_out)
+// Exclusive scan of the ntile uint32 newline counts into uint64 bases, in three small launches: sums of 4096
+// counts per workgroup, a scan of those sums by one workgroup (which also sets up the state of the call: the
+// number of newlines is known there), and the bases from the scanned sums.  (ONE workgroup over all counts has
+// the bandwidth and the latency of one compute unit: rounds of 16,384 counts took 0.044 ms on 83 K tiles, rounds
+// of 4,096 0.060 ms, one round with 81 consecutive counts per thread 0.055 ms.)
+constexpr uint32_t TS_PER = 16, TS_TILE = PB * TS_PER;      // counts per thread and per workgroup
+
+__device__ __forceinline__ void tile_counts16(const uint32_t* __restrict__ cnt, uint64_t ntile, uint64_t i, uint32_t (&c)[TS_PER])
 {
-    constexpr int PER = 16;
-    __shared__ uint64_t s_wave[16];
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint64_t carry = 0;
-    for (uint64_t i0 = 0; i0 < ntile; i0 += 1024 * PER) {
-        const uint64_t i = i0 + (uint64_t)PER * threadIdx.x;
-        uint32_t c[PER];
-        if (i + PER <= ntile) {                                      // (cnt is 256-byte aligned, i a multiple of 16)
+    if (i + TS_PER <= ntile) {                                       // (cnt is 256-byte aligned, i a multiple of 16)
 #pragma unroll
-            for (int k = 0; k < PER; k += 4) {
-                const uint4 v = *reinterpret_cast<const uint4*>(cnt + i + k);
-                c[k] = v.x; c[k + 1] = v.y; c[k + 2] = v.z; c[k + 3] = v.w;
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < PER; k++) c[k] = i + k < ntile ? cnt[i + k] : 0u;
+        for (uint32_t k = 0; k < TS_PER; k += 4) {
+            const uint4 v = *reinterpret_cast<const uint4*>(cnt + i + k);
+            c[k] = v.x; c[k + 1] = v.y; c[k + 2] = v.z; c[k + 3] = v.w;
         }
-        uint32_t mine = 0;                                           // < 2^32: a tile holds at most TILE newlines
+    } else {
 #pragma unroll
-        for (int k = 0; k < PER; k++) mine += c[k];
-        uint64_t inc = mine;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint64_t t = ((uint64_t)(uint32_t)__shfl_up((int)(uint32_t)(inc >> 32), d) << 32) | (uint32_t)__shfl_up((int)(uint32_t)inc, d);
-            if ((int)lane >= d) inc += t;
-        }
-        if (lane == 63) s_wave[wave] = inc;
-        __syncthreads();
-        uint64_t before = carry, all = 0;
-#pragma unroll
-        for (uint32_t w = 0; w < 16; w++) {
-            if (w < wave) before += s_wave[w];
-            all += s_wave[w];
-        }
-        __syncthreads();
-        uint64_t run = before + inc - mine;
-        if (i + PER <= ntile) {
-#pragma unroll
-            for (int k = 0; k < PER; k += 2) {
-                const uint64_t r0 = run, r1 = run + c[k];
-                *reinterpret_cast<uint4*>(base + i + k) = make_uint4((uint32_t)r0, (uint32_t)(r0 >> 32), (uint32_t)r1, (uint32_t)(r1 >> 32));
-                run = r1 + c[k + 1];
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < PER; k++) {
-                if (i + k < ntile) base[i + k] = run;
-                run += c[k];
-            }
-        }
-        carry += all;
+        for (uint32_t k = 0; k < TS_PER; k++) c[k] = i + k < ntile ? cnt[i + k] : 0u;
     }
-    if (threadIdx.x == 0) { *n_out = carry; base[ntile] = carry; }
+}
+
+__global__ __launch_bounds__(PB) void k_tiles_partials(const uint32_t* __restrict__ cnt, uint64_t ntile, uint64_t* __restrict__ tpart)
+{
+    __shared__ uint64_t s_wave[PB / 64];
+    uint32_t c[TS_PER];
+    tile_counts16(cnt, ntile, (uint64_t)blockIdx.x * TS_TILE + (uint64_t)threadIdx.x * TS_PER, c);
+    uint64_t mine = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < TS_PER; k++) mine += c[k];
+    for (int d = 1; d < 64; d <<= 1) mine += __shfl_xor((unsigned long long)mine, d);
+    if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t t = 0;
+        for (uint32_t w = 0; w < PB / 64; w++) t += s_wave[w];
+        tpart[blockIdx.x] = t;
+    }
+}
+
+__global__ __launch_bounds__(PB) void k_tiles_apply(const uint32_t* __restrict__ cnt, uint64_t ntile, const uint64_t* __restrict__ tpart,
+                                                    uint64_t* __restrict__ base)
+{
+    __shared__ uint64_t s_wave[PB / 64];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t i = (uint64_t)blockIdx.x * TS_TILE + (uint64_t)threadIdx.x * TS_PER;
+    uint32_t c[TS_PER];
+    tile_counts16(cnt, ntile, i, c);
+    uint64_t mine = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < TS_PER; k++) mine += c[k];
+    uint64_t inc = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint64_t t = __shfl_up((unsigned long long)inc, d);
+        if ((int)lane >= d) inc += t;
+    }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    uint64_t run = tpart[blockIdx.x] + inc - mine;
+    for (uint32_t w = 0; w < wave; w++) run += s_wave[w];
+    if (i + TS_PER <= ntile) {
+#pragma unroll
+        for (uint32_t k = 0; k < TS_PER; k += 2) {
+            const uint64_t r0 = run, r1 = run + c[k];
+            *reinterpret_cast<uint4*>(base + i + k) = make_uint4((uint32_t)r0, (uint32_t)(r0 >> 32), (uint32_t)r1, (uint32_t)(r1 >> 32));
+            run = r1 + c[k + 1];
+        }
+    } else {
+#pragma unroll
+        for (uint32_t k = 0; k < TS_PER; k++) {
+            if (i + k < ntile) base[i + k] = run;
+            run += c[k];
+        }
+    }
 }
 
 // ---- pass 2: line table ------------------------------------------------------------------
@@ -282,10 +295,40 @@ struct ParseState {            // device scratch shared by the passes of one cal
     uint64_t copy_lo, copy_hi;             // FASTA: the sequence lines i of the block's records are those with copy_lo < i < copy_hi
 };
 
-__global__ void k_parse_init(ParseState* st, uint64_t n, int final, const uint8_t* __restrict__ text,
-                             uint64_t max_lines)
+// One workgroup: the sums of k_tiles_partials scanned in place (exclusive), the number of newlines, and with it
+// the state every later pass starts from.
+__global__ __launch_bounds__(1024) void k_tiles_top(uint64_t* __restrict__ tpart, uint64_t ntpart, uint64_t ntile,
+                                                    uint64_t* __restrict__ tile_base, ParseState* st, uint64_t n, int final,
+                                                    const uint8_t* __restrict__ text, uint64_t max_lines)
 {
-    uint64_t nl = st->n_nl;
+    __shared__ uint64_t s_wave[16];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint64_t carry = 0;
+    for (uint64_t i0 = 0; i0 < ntpart; i0 += 1024) {
+        const uint64_t i = i0 + threadIdx.x;
+        const uint64_t mine = i < ntpart ? tpart[i] : 0;
+        uint64_t inc = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint64_t t = __shfl_up((unsigned long long)inc, d);
+            if ((int)lane >= d) inc += t;
+        }
+        if (lane == 63) s_wave[wave] = inc;
+        __syncthreads();
+        uint64_t before = carry, all = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < 16; w++) {
+            if (w < wave) before += s_wave[w];
+            all += s_wave[w];
+        }
+        __syncthreads();
+        if (i < ntpart) tpart[i] = before + inc - mine;
+        carry += all;
+    }
+    if (threadIdx.x != 0) return;
+    const uint64_t nl = carry;
+    tile_base[ntile] = nl;
+    st->n_nl = nl;
     uint64_t lines = nl;
     if (final && n != 0 && text[n - 1] != '\n') lines++;          // unterminated last line
     if (lines > max_lines) lines = max_lines;                      // reported as capacity error later
@@ -299,6 +342,16 @@ __global__ void k_parse_init(ParseState* st, uint64_t n, int final, const uint8_
     st->total.heads = 0;
     st->first_head = ~0ull; st->last_head = ~0ull;
     st->copy_lo = ~0ull; st->copy_hi = 0;
+}
+
+// the three launches
+static void launch_tile_scan(const uint32_t* tile_count, uint64_t ntile, uint64_t* tile_base, uint64_t* tpart, ParseState* st,
+                             uint64_t n, int final, const uint8_t* text, uint64_t max_lines, hipStream_t s)
+{
+    const uint64_t ntpart = (ntile + TS_TILE - 1) / TS_TILE;
+    if (ntpart) hipLaunchKernelGGL(k_tiles_partials, dim3((uint32_t)ntpart), dim3(PB), 0, s, tile_count, ntile, tpart);
+    hipLaunchKernelGGL(k_tiles_top, dim3(1), dim3(1024), 0, s, tpart, ntpart, ntile, tile_base, st, n, final, text, max_lines);
+    if (ntpart) hipLaunchKernelGGL(k_tiles_apply, dim3((uint32_t)ntpart), dim3(PB), 0, s, tile_count, ntile, tpart, tile_base);
 }
 
 // Line i: its start, its length without the trailing '\r's, and its first byte (0 if empty).
@@ -1258,7 +1311,7 @@ static inline uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a
 
 // Workspace layout for `max_lines` lines and `text_bytes` of text (all sections 256-byte aligned).
 struct ParseLayout {
-    uint64_t state, tile_count, tile_base, tile_last, nl_tile, nlpos, line_start, line_len, line_head, line_dst, part, end;
+    uint64_t state, tile_count, tile_base, tile_last, tile_part, nl_tile, nlpos, line_start, line_len, line_head, line_dst, part, end;
     ParseLayout(uint64_t text_bytes, uint64_t max_lines)
     {
         const uint64_t ntile = (text_bytes + TILE - 1) / TILE + 1;
@@ -1268,6 +1321,7 @@ struct ParseLayout {
         tile_count = o; o = align_up(o + ntile * 4, 256);
         tile_base = o; o = align_up(o + (ntile + 1) * 8, 256);
         tile_last = o; o = align_up(o + ntile * 8, 256);
+        tile_part = o; o = align_up(o + (ntile / TS_TILE + 2) * 8, 256);
         nl_tile = o; o = align_up(o + ntile * (uint64_t)TILE * 4, 256);      // address space: only the entries that exist are touched
         nlpos = o; o = align_up(o + max_lines * 8, 256);
         line_start = o; o = align_up(o + max_lines * 8, 256);
@@ -1315,8 +1369,7 @@ static hipError_t launch_parse_t(const uint8_t* text, uint64_t n, int final, uin
     const uint32_t gc = capped((lines_cap * 8 + PB - 1) / PB);
 
     hipLaunchKernelGGL(k_nl_index, dim3(gt), dim3(PB), 0, s, text, n, tile_count, tile_last, nl_tile);
-    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, tile_count, ntile, tile_base, &st->n_nl);
-    hipLaunchKernelGGL(k_parse_init, dim3(1), dim3(1), 0, s, st, n, final, text, max_lines);
+    launch_tile_scan(tile_count, ntile, tile_base, reinterpret_cast<uint64_t*>(ws + lay.tile_part), st, n, final, text, max_lines, s);
     hipLaunchKernelGGL((k_line_table<FASTQ>), dim3(gl < 2048 ? gl : 2048), dim3(PB), 0, s, text, n, ntile, nl_tile, tile_count, tile_base,
                        tile_last, st, nlpos, line_start, line_len, line_head, 0, max_records, name_pos, name_len);
     hipLaunchKernelGGL((k_line_partials<FASTQ>), dim3((uint32_t)npart), dim3(PB), 0, s, line_len, line_head, st, part);
@@ -1424,8 +1477,7 @@ hipError_t launch_parse_wrapped(const uint8_t* text, uint64_t n, int final, uint
     if (e != hipSuccess) return e;
     // the line table as for FASTA, with every line's first byte in place of the head flag
     hipLaunchKernelGGL(k_nl_index, dim3(gt), dim3(PB), 0, s, text, n, tile_count, tile_last, nl_tile);
-    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, s, tile_count, ntile, tile_base, &st->n_nl);
-    hipLaunchKernelGGL(k_parse_init, dim3(1), dim3(1), 0, s, st, n, final, text, max_lines);
+    launch_tile_scan(tile_count, ntile, tile_base, reinterpret_cast<uint64_t*>(ws + lay.tile_part), st, n, final, text, max_lines, s);
     hipLaunchKernelGGL((k_line_table<false>), dim3(gl < 2048 ? gl : 2048), dim3(PB), 0, s, text, n, ntile, nl_tile, tile_count, tile_base,
                        tile_last, st, nlpos, line_start, line_len, line_first, 1, 0, nullptr, nullptr);
     uint64_t* sums[3] = {cP, cPlus, cNb};
