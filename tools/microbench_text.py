@@ -121,7 +121,8 @@ def run(kind):
     print("== %s: %d records x %d, text %.2f GB" % (kind, nrec, L, n / 1e9))
     with torch.cuda.stream(st):
         for name, (fn, nbytes) in cases.items():
-            if os.environ.get("DENSE_NAMES") and name.startswith("format fx2tab"):
+            if (os.environ.get("DENSE_NAMES") and name.startswith("format fx2tab")) or \
+                    (os.environ.get("DENSE_NAMES") == "all" and name.startswith("format seq")):
                 dense_names()
             for _ in range(2): fn()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
