@@ -176,26 +176,31 @@ __global__ __launch_bounds__(PB) void k_nl_index(const uint8_t* __restrict__ tex
     }
     const uint64_t ex = before + inc - mine;             // per row: newlines of the row before this thread's chunk
     uint32_t* mine_out = nl_tile + (uint64_t)blockIdx.x * TILE;
-    uint32_t run = 0;
     const uint32_t count = (uint32_t)((all & 0xffffu) + ((all >> 16) & 0xffffu) + ((all >> 32) & 0xffffu) + ((all >> 48) & 0xffffu));
+    // where the thread's first entry of each of its four chunks goes: the rows before, and the row's threads before
+    uint32_t kb[NLU], run = 0;
 #pragma unroll
     for (int u = 0; u < NLU; u++) {
-        const uint64_t o = t0 + (uint64_t)(u * PB + threadIdx.x) * 16;
-        uint32_t k = run + (uint32_t)((ex >> (16 * u)) & 0xffffu);
-        uint32_t mm = m[u];
-        while (mm) {
-            const uint32_t bit = __builtin_ctz(mm);
-            mm &= mm - 1;
-            const uint64_t p = o + bit;
-            const uint32_t q = (uint32_t)(p - t0);         // the neighbours outside the tile come from memory
-            const uint32_t prev = q > 0 ? s_byte[q - 1] : (p > 0 ? text[p - 1] : 0);
-            const uint32_t next = p + 1 >= n ? 0 : (q + 1 < TILE ? s_byte[q + 1] : text[p + 1]);
-            const uint32_t e32 = q | (next << NLT_POS_BITS) | (prev == '\r' ? NLT_CR : 0u);
-            mine_out[k] = e32;
-            if (k + 1 == count) tile_last[blockIdx.x] = nl_entry64(e32, t0);
-            k++;
-        }
+        kb[u] = run + (uint32_t)((ex >> (16 * u)) & 0xffffu);
         run += (uint32_t)((all >> (16 * u)) & 0xffffu);
+    }
+    // ONE loop over the newlines of all four chunks (a lane finds a newline in one chunk out of five or so: four
+    // loops run as long as the busiest lane of each chunk row, one loop as long as the busiest lane overall)
+    const uint64_t mall = (uint64_t)m[0] | ((uint64_t)m[1] << 16) | ((uint64_t)m[2] << 32) | ((uint64_t)m[3] << 48);
+    uint64_t mm = mall;
+    while (mm) {
+        const uint32_t bit = (uint32_t)__builtin_ctzll(mm);
+        mm &= mm - 1;
+        const uint32_t u = bit >> 4, b = bit & 15u;
+        const uint32_t lower = (uint32_t)(mall >> (bit & 48u)) & ((1u << b) - 1u);       // the chunk's newlines before this one
+        const uint32_t k = (u == 0 ? kb[0] : (u == 1 ? kb[1] : (u == 2 ? kb[2] : kb[3]))) + (uint32_t)__builtin_popcount(lower);
+        const uint32_t q = ((u * PB + threadIdx.x) << 4) + b;              // position in the tile
+        const uint64_t p = t0 + q;                          // the neighbours outside the tile come from memory
+        const uint32_t prev = q > 0 ? s_byte[q - 1] : (p > 0 ? text[p - 1] : 0);
+        const uint32_t next = p + 1 >= n ? 0 : (q + 1 < TILE ? s_byte[q + 1] : text[p + 1]);
+        const uint32_t e32 = q | (next << NLT_POS_BITS) | (prev == '\r' ? NLT_CR : 0u);
+        mine_out[k] = e32;
+        if (k + 1 == count) tile_last[blockIdx.x] = nl_entry64(e32, t0);
     }
     if (threadIdx.x == 0) tile_count[blockIdx.x] = count;
 }
