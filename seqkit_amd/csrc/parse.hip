@@ -569,23 +569,36 @@ __device__ __forceinline__ void line_items(const uint32_t* __restrict__ line_len
 }
 
 // Four-line FASTQ: the items of the scan are RECORDS (lines 4 r .. 4 r + 3, their lengths one 16-byte load):
-// bytes = the length of the sequence line, heads = 1.  `base` counts records.  With `check`, a quality line that
-// is not as long as its sequence line is reported (complete records only).
+// bytes = the length of the sequence line, heads = 1.  `base` is the thread's first record (SCAN_ITEMS consecutive
+// ones are its items).  The loads are dealt the other way round -- the lanes of one load take consecutive records,
+// 1 KiB per instruction, where a thread's own eight records lie 128 bytes from its neighbour's -- and the
+// sequence lengths change hands through LDS.  With `check`, a quality line that is not as long as its sequence
+// line is reported (complete records only).
 __device__ __forceinline__ void record_items(const uint32_t* __restrict__ line_len, uint64_t base, uint64_t nlines, ParseState* st,
-                                             bool check, LineSum* v)
+                                             bool check, LineSum* v, uint32_t* s_len)
 {
+    const uint64_t block0 = base - (uint64_t)threadIdx.x * SCAN_ITEMS;      // the workgroup's first record
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; k++) {
-        const uint64_t i0 = 4 * (base + k);
-        v[k] = LineSum{0, 0};
+        const uint64_t i0 = 4 * (block0 + (uint64_t)k * PB + threadIdx.x);
+        uint32_t len = 0;
         if (i0 + 4 <= nlines) {
             const uint4 l = *reinterpret_cast<const uint4*>(line_len + i0);
-            v[k].bytes = l.y; v[k].heads = 1;
+            len = l.y;
             if (check && l.w != l.y) atomicMin(&st->err_line, (unsigned long long)(i0 + 3));
-        } else if (i0 < nlines) {                         // the block ends inside the record
-            v[k].heads = 1;
-            if (i0 + 1 < nlines) v[k].bytes = line_len[i0 + 1];
+        } else if (i0 + 1 < nlines) {                     // the block ends inside the record
+            len = line_len[i0 + 1];
         }
+        s_len[k * PB + threadIdx.x] = len;
+    }
+    __syncthreads();
+    const uint4 a = *reinterpret_cast<const uint4*>(s_len + threadIdx.x * SCAN_ITEMS);
+    const uint4 b = *reinterpret_cast<const uint4*>(s_len + threadIdx.x * SCAN_ITEMS + 4);
+    const uint32_t l[SCAN_ITEMS] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) {
+        v[k].bytes = l[k];
+        v[k].heads = 4 * (base + k) < nlines ? 1u : 0u;
     }
 }
 
@@ -601,7 +614,8 @@ __global__ __launch_bounds__(PB) void k_line_partials(const uint32_t* __restrict
     uint64_t b = 0; uint32_t h = 0;
     LineSum v[SCAN_ITEMS];
     uint32_t len[SCAN_ITEMS];
-    if (FASTQ) record_items(line_len, base, nlines, st, true, v);      // (a quality line must be as long as its sequence line)
+    __shared__ __attribute__((aligned(16))) uint32_t s_len[FASTQ ? SCAN_TILE : 4];
+    if (FASTQ) record_items(line_len, base, nlines, st, true, v, s_len);      // (a quality line must be as long as its sequence line)
     else line_items<FASTQ>(line_len, line_head, base, nlines, v, len);
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; k++) { b += v[k].bytes; h += v[k].heads; }
@@ -691,7 +705,8 @@ __global__ __launch_bounds__(PB) void k_line_scan(const uint32_t* __restrict__ l
     LineSum v[SCAN_ITEMS];
     uint32_t len[SCAN_ITEMS];
     uint64_t b = 0; uint32_t h = 0;
-    if (FASTQ) record_items(line_len, base, nlines, st, false, v);
+    __shared__ __attribute__((aligned(16))) uint32_t s_len[FASTQ ? SCAN_TILE : 4];
+    if (FASTQ) record_items(line_len, base, nlines, st, false, v, s_len);
     else line_items<FASTQ>(line_len, line_head, base, nlines, v, len);
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; k++) { b += v[k].bytes; h += v[k].heads; }
