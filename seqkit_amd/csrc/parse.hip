@@ -25,6 +25,7 @@
 //          reported as a format error by this parser.)
 // A block that is not the last of its file ends in an incomplete record: `consumed` tells the
 // caller where that record starts, so that the next block can begin there.
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -390,12 +391,14 @@ __device__ __forceinline__ uint64_t newline_before_tile(uint64_t t, const uint32
 
 constexpr uint32_t LT_TILES = 8;             // tiles of newline entries a workgroup of the line table takes at a time
 
-template <bool FASTQ>
+// POS: the type of the tables of positions in the text and in the planes (line_start, line_dst) -- 32 bits for a
+// text of less than 4 GiB, which every position then fits
+template <bool FASTQ, typename POS>
 __global__ __launch_bounds__(PB) void k_line_table(const uint8_t* __restrict__ text, uint64_t n, uint64_t ntile,
                                                    const uint32_t* __restrict__ nl_tile, const uint32_t* __restrict__ tile_count,
                                                    const uint64_t* __restrict__ tile_base, const uint64_t* __restrict__ tile_last,
                                                    ParseState* st, uint64_t* __restrict__ nlpos,
-                                                   uint64_t* __restrict__ line_start, uint32_t* __restrict__ line_len,
+                                                   POS* __restrict__ line_start, uint32_t* __restrict__ line_len,
                                                    uint8_t* __restrict__ line_head, int raw_first,
                                                    uint64_t max_records, uint64_t* __restrict__ name_pos, uint32_t* __restrict__ name_len)
 {
@@ -476,7 +479,7 @@ __global__ __launch_bounds__(PB) void k_line_table(const uint8_t* __restrict__ t
                 if (len) { last = i > last ? i : last; any = true; }
                 if (len > LONG_LINE) atomicAdd(&st->n_long, 1u);
                 if (bad && i < err) err = i;
-                line_start[i] = ls;
+                line_start[i] = (POS)ls;
                 line_len[i] = len;
                 if (!FASTQ) line_head[i] = raw_first ? c : (head ? 1 : 0);     // (raw_first: the line's first byte, for the wrapped-FASTQ passes)
                 // four-line FASTQ: line 4 r is the head of record r, whatever comes of the block (entries beyond the
@@ -690,11 +693,11 @@ __global__ __launch_bounds__(1024) void k_scan_partials(LineSum* __restrict__ pa
 // line of rank r opens record r; FASTA: a non-blank line before the first head line is a format error).  Records
 // beyond `nrec_cap` -- the number of complete records, known before this pass from the head count or the line
 // count, and never more than the tables hold -- are not written.
-template <bool FASTQ>
+template <bool FASTQ, typename POS>
 __global__ __launch_bounds__(PB) void k_line_scan(const uint32_t* __restrict__ line_len,
                                                   const uint8_t* __restrict__ line_head, ParseState* st,
-                                                  const LineSum* __restrict__ part, uint64_t* __restrict__ line_dst,
-                                                  const uint64_t* __restrict__ line_start,
+                                                  const LineSum* __restrict__ part, POS* __restrict__ line_dst,
+                                                  const POS* __restrict__ line_start,
                                                   uint64_t max_records, uint64_t* __restrict__ offsets,
                                                   uint64_t* __restrict__ name_pos, uint32_t* __restrict__ name_len)
 {
@@ -740,25 +743,32 @@ __global__ __launch_bounds__(PB) void k_line_scan(const uint32_t* __restrict__ l
 #pragma unroll
         for (int k = 0; k < SCAN_ITEMS; k++) {
             if (v[k].heads) {
-                if (r[k] < nrec_cap) { offsets[r[k]] = d[k]; name_pos[r[k]] = line_start[base + k] + 1; name_len[r[k]] = len[k] - 1; }
+                if (r[k] < nrec_cap) { offsets[r[k]] = d[k]; name_pos[r[k]] = (uint64_t)line_start[base + k] + 1; name_len[r[k]] = len[k] - 1; }
                 if (r[k] == 0) st->first_head = base + k;             // (one writer each)
                 if (r[k] + 1 == nheads) st->last_head = base + k;
             } else if (!FASTQ && r[k] == 0 && len[k] != 0) {
                 atomicMin(&st->err_line, (unsigned long long)(base + k));
             }
         }
+        if constexpr (sizeof(POS) == 8) {
 #pragma unroll
-        for (int k = 0; k < SCAN_ITEMS; k += 2)
-            *reinterpret_cast<uint4*>(line_dst + base + k) =
-                make_uint4((uint32_t)d[k], (uint32_t)(d[k] >> 32), (uint32_t)d[k + 1], (uint32_t)(d[k + 1] >> 32));
+            for (int k = 0; k < SCAN_ITEMS; k += 2)
+                *reinterpret_cast<uint4*>(line_dst + base + k) =
+                    make_uint4((uint32_t)d[k], (uint32_t)(d[k] >> 32), (uint32_t)d[k + 1], (uint32_t)(d[k + 1] >> 32));
+        } else {
+#pragma unroll
+            for (int k = 0; k < SCAN_ITEMS; k += 4)
+                *reinterpret_cast<uint4*>(line_dst + base + k) =
+                    make_uint4((uint32_t)d[k], (uint32_t)d[k + 1], (uint32_t)d[k + 2], (uint32_t)d[k + 3]);
+        }
         return;
     }
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; k++) {
         if (base + k < nlines) {
-            line_dst[base + k] = rb;
+            line_dst[base + k] = (POS)rb;
             if (v[k].heads) {
-                if (rh < nrec_cap) { offsets[rh] = rb; name_pos[rh] = line_start[base + k] + 1; name_len[rh] = len[k] - 1; }
+                if (rh < nrec_cap) { offsets[rh] = rb; name_pos[rh] = (uint64_t)line_start[base + k] + 1; name_len[rh] = len[k] - 1; }
                 if (rh == 0) st->first_head = base + k;
                 if (rh + 1 == nheads) st->last_head = base + k;
             } else if (!FASTQ && rh == 0 && len[k] != 0) {
@@ -771,8 +781,9 @@ __global__ __launch_bounds__(PB) void k_line_scan(const uint32_t* __restrict__ l
 
 // ---- pass 4: decide, emit, copy -----------------------------------------------------------
 
+template <typename POS>
 __device__ __forceinline__ uint64_t start_of_line(uint64_t k, uint64_t nlines, uint64_t n_nl, uint64_t n,
-                                                  const uint64_t* __restrict__ line_start,
+                                                  const POS* __restrict__ line_start,
                                                   const uint64_t* __restrict__ nlpos)
 {
     if (k < nlines) return line_start[k];
@@ -781,10 +792,10 @@ __device__ __forceinline__ uint64_t start_of_line(uint64_t k, uint64_t nlines, u
 }
 
 // One thread: how many complete records the block holds and where the rest starts.
-template <bool FASTQ>
+template <bool FASTQ, typename POS>
 __global__ void k_parse_decide(ParseState* st, uint64_t n, int final, uint64_t max_lines,
-                               const uint64_t* __restrict__ nlpos, const uint64_t* __restrict__ line_start,
-                               const uint64_t* __restrict__ line_dst,
+                               const uint64_t* __restrict__ nlpos, const POS* __restrict__ line_start,
+                               const POS* __restrict__ line_dst,
                                uint64_t max_records, uint64_t* __restrict__ offsets)
 {
     const uint64_t L = st->nlines, n_nl = st->n_nl;
@@ -890,13 +901,13 @@ __device__ __forceinline__ void copy_line(uint8_t* __restrict__ out, const uint8
 // to k_parse_copy_long.
 constexpr uint32_t PC_STAGE = 3584;
 
-template <bool FASTQ>
+template <bool FASTQ, typename POS>
 __global__ __launch_bounds__(PB) void k_parse_copy(const ParseState* st, uint64_t max_records, uint64_t seq_capacity,
                                                    const uint8_t* __restrict__ text,
-                                                   const uint64_t* __restrict__ line_start,
+                                                   const POS* __restrict__ line_start,
                                                    const uint32_t* __restrict__ line_len,
                                                    const uint8_t* __restrict__ line_head,
-                                                   const uint64_t* __restrict__ line_dst,
+                                                   const POS* __restrict__ line_dst,
                                                    const uint64_t* __restrict__ offsets,
                                                    uint8_t* __restrict__ seq, uint8_t* __restrict__ qual)
 {
@@ -1027,13 +1038,13 @@ __global__ __launch_bounds__(PB) void k_parse_copy(const ParseState* st, uint64_
 // The lines longer than LONG_LINE (unwrapped chromosome-length sequences): workgroups own
 // aligned windows of the text, and only the lines that hold a window's first and last byte can be
 // that long, so such a line is copied by as many workgroups as it has windows.
-template <bool FASTQ>
+template <bool FASTQ, typename POS>
 __global__ __launch_bounds__(PB) void k_parse_copy_long(const ParseState* st, uint64_t max_records, uint64_t seq_capacity,
                                                         const uint8_t* __restrict__ text, uint64_t n,
-                                                        const uint64_t* __restrict__ line_start,
+                                                        const POS* __restrict__ line_start,
                                                         const uint32_t* __restrict__ line_len,
                                                         const uint8_t* __restrict__ line_head,
-                                                        const uint64_t* __restrict__ line_dst,
+                                                        const POS* __restrict__ line_dst,
                                                         const uint64_t* __restrict__ offsets,
                                                         uint8_t* __restrict__ seq, uint8_t* __restrict__ qual)
 {
@@ -1358,7 +1369,7 @@ uint64_t parse_workspace_size(uint64_t text_bytes, uint64_t max_lines)
     return ParseLayout(text_bytes, max_lines).end;
 }
 
-template <bool FASTQ>
+template <bool FASTQ, typename POS>
 static hipError_t launch_parse_t(const uint8_t* text, uint64_t n, int final, uint8_t* seq, uint8_t* qual,
                                  uint64_t seq_capacity, uint64_t* offsets, uint64_t* name_pos, uint32_t* name_len,
                                  uint64_t max_records, uint8_t* ws, uint64_t max_lines, ParseResult* res, hipStream_t s)
@@ -1370,10 +1381,10 @@ static hipError_t launch_parse_t(const uint8_t* text, uint64_t n, int final, uin
     uint64_t* tile_last = reinterpret_cast<uint64_t*>(ws + lay.tile_last);
     uint32_t* nl_tile = reinterpret_cast<uint32_t*>(ws + lay.nl_tile);
     uint64_t* nlpos = reinterpret_cast<uint64_t*>(ws + lay.nlpos);
-    uint64_t* line_start = reinterpret_cast<uint64_t*>(ws + lay.line_start);
+    POS* line_start = reinterpret_cast<POS*>(ws + lay.line_start);     // (the sections are sized for 64-bit entries)
     uint32_t* line_len = reinterpret_cast<uint32_t*>(ws + lay.line_len);
     uint8_t* line_head = ws + lay.line_head;
-    uint64_t* line_dst = reinterpret_cast<uint64_t*>(ws + lay.line_dst);
+    POS* line_dst = reinterpret_cast<POS*>(ws + lay.line_dst);
     LineSum* part = reinterpret_cast<LineSum*>(ws + lay.part);
 
     const uint64_t ntile = (n + TILE - 1) / TILE;
@@ -1390,17 +1401,17 @@ static hipError_t launch_parse_t(const uint8_t* text, uint64_t n, int final, uin
 
     hipLaunchKernelGGL(k_nl_index, dim3(gt), dim3(PB), 0, s, text, n, tile_count, tile_last, nl_tile);
     launch_tile_scan(tile_count, ntile, tile_base, reinterpret_cast<uint64_t*>(ws + lay.tile_part), st, n, final, text, max_lines, s);
-    hipLaunchKernelGGL((k_line_table<FASTQ>), dim3(gl < 2048 ? gl : 2048), dim3(PB), 0, s, text, n, ntile, nl_tile, tile_count, tile_base,
+    hipLaunchKernelGGL((k_line_table<FASTQ, POS>), dim3(gl < 2048 ? gl : 2048), dim3(PB), 0, s, text, n, ntile, nl_tile, tile_count, tile_base,
                        tile_last, st, nlpos, line_start, line_len, line_head, 0, max_records, name_pos, name_len);
     hipLaunchKernelGGL((k_line_partials<FASTQ>), dim3((uint32_t)npart), dim3(PB), 0, s, line_len, line_head, st, part);
     hipLaunchKernelGGL((k_scan_partials<FASTQ>), dim3(1), dim3(1024), 0, s, part, npart, st, final, max_records);
-    hipLaunchKernelGGL((k_line_scan<FASTQ>), dim3((uint32_t)npart), dim3(PB), 0, s, line_len, line_head, st, part, line_dst,
+    hipLaunchKernelGGL((k_line_scan<FASTQ, POS>), dim3((uint32_t)npart), dim3(PB), 0, s, line_len, line_head, st, part, line_dst,
                        line_start, max_records, offsets, name_pos, name_len);
-    hipLaunchKernelGGL((k_parse_decide<FASTQ>), dim3(1), dim3(1), 0, s, st, n, final, max_lines, nlpos, line_start, line_dst,
+    hipLaunchKernelGGL((k_parse_decide<FASTQ, POS>), dim3(1), dim3(1), 0, s, st, n, final, max_lines, nlpos, line_start, line_dst,
                        max_records, offsets);
-    hipLaunchKernelGGL((k_parse_copy<FASTQ>), dim3(gc), dim3(PB), 0, s, st, max_records, seq_capacity, text, line_start,
+    hipLaunchKernelGGL((k_parse_copy<FASTQ, POS>), dim3(gc), dim3(PB), 0, s, st, max_records, seq_capacity, text, line_start,
                        line_len, line_head, line_dst, offsets, seq, qual);
-    hipLaunchKernelGGL((k_parse_copy_long<FASTQ>), dim3(1024), dim3(PB), 0, s, st, max_records, seq_capacity, text, n,
+    hipLaunchKernelGGL((k_parse_copy_long<FASTQ, POS>), dim3(1024), dim3(PB), 0, s, st, max_records, seq_capacity, text, n,
                        line_start, line_len, line_head, line_dst, offsets, seq, qual);
     hipLaunchKernelGGL(k_parse_finish, dim3(1), dim3(1), 0, s, st, max_records, seq_capacity, res);
     return hipGetLastError();
@@ -1411,10 +1422,18 @@ hipError_t launch_parse(int fastq, const uint8_t* text, uint64_t n, int final, u
                         uint64_t max_records, void* workspace, uint64_t max_lines, ParseResult* res, hipStream_t s)
 {
     uint8_t* ws = static_cast<uint8_t*>(workspace);
-    return fastq ? launch_parse_t<true>(text, n, final, seq, qual, seq_capacity, offsets, name_pos, name_len,
-                                        max_records, ws, max_lines, res, s)
-                 : launch_parse_t<false>(text, n, final, seq, qual, seq_capacity, offsets, name_pos, name_len,
-                                         max_records, ws, max_lines, res, s);
+    // a text of less than 4 GiB: every position in it and in the planes fits 32 bits, and the tables of positions
+    // are half the bytes
+    // (SKH_PARSE_POS64, read at every call: the 64-bit tables for a small text too -- tests of that path)
+    if (n <= 0xffffffffull && getenv("SKH_PARSE_POS64") == nullptr)
+        return fastq ? launch_parse_t<true, uint32_t>(text, n, final, seq, qual, seq_capacity, offsets, name_pos, name_len,
+                                                      max_records, ws, max_lines, res, s)
+                     : launch_parse_t<false, uint32_t>(text, n, final, seq, qual, seq_capacity, offsets, name_pos, name_len,
+                                                       max_records, ws, max_lines, res, s);
+    return fastq ? launch_parse_t<true, uint64_t>(text, n, final, seq, qual, seq_capacity, offsets, name_pos, name_len,
+                                                  max_records, ws, max_lines, res, s)
+                 : launch_parse_t<false, uint64_t>(text, n, final, seq, qual, seq_capacity, offsets, name_pos, name_len,
+                                                   max_records, ws, max_lines, res, s);
 }
 
 // Workspace of the wrapped-FASTQ passes, behind the parser's own (all sections 256-byte aligned).
@@ -1498,7 +1517,7 @@ hipError_t launch_parse_wrapped(const uint8_t* text, uint64_t n, int final, uint
     // the line table as for FASTA, with every line's first byte in place of the head flag
     hipLaunchKernelGGL(k_nl_index, dim3(gt), dim3(PB), 0, s, text, n, tile_count, tile_last, nl_tile);
     launch_tile_scan(tile_count, ntile, tile_base, reinterpret_cast<uint64_t*>(ws + lay.tile_part), st, n, final, text, max_lines, s);
-    hipLaunchKernelGGL((k_line_table<false>), dim3(gl < 2048 ? gl : 2048), dim3(PB), 0, s, text, n, ntile, nl_tile, tile_count, tile_base,
+    hipLaunchKernelGGL((k_line_table<false, uint64_t>), dim3(gl < 2048 ? gl : 2048), dim3(PB), 0, s, text, n, ntile, nl_tile, tile_count, tile_base,
                        tile_last, st, nlpos, line_start, line_len, line_first, 1, 0, nullptr, nullptr);
     uint64_t* sums[3] = {cP, cPlus, cNb};
     for (int kind = 0; kind < 3; kind++) {

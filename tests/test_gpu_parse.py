@@ -421,3 +421,24 @@ def test_wrapped_fastq_damaged_texts(env, tmp_path):
             assert res.status == capi.PARSE_OK and res.consumed == len(text), (case, kind, res.status, text)
             assert records_of(names, seq, qual, offs) == want, (case, kind, text)
     assert n_ok > 50 and n_bad > 50, (n_ok, n_bad)
+
+
+@pytest.mark.parametrize("fmt_name", ["fasta", "fastq"])
+def test_wide_position_tables(env, tmp_path, fmt_name, monkeypatch):
+    """A text of 4 GiB or more keeps its tables of positions in 64 bits; SKH_PARSE_POS64 asks for that form on a small
+    text: same records, whole and block by block."""
+    capi = env["capi"]
+    rng = np.random.default_rng(11)
+    fmt = capi.FASTA if fmt_name == "fasta" else capi.FASTQ
+    text = random_fasta(rng, 3000, False) if fmt_name == "fasta" else random_fastq(rng, 3000, False)
+    narrow = gpu_parse(env, text, fmt, True)
+    monkeypatch.setenv("SKH_PARSE_POS64", "1")
+    wide = gpu_parse(env, text, fmt, True)
+    assert narrow[0].status == wide[0].status == capi.PARSE_OK and narrow[0].nrec == wide[0].nrec
+    assert records_of(*narrow[1:]) == records_of(*wide[1:])
+    check_text(env, tmp_path, text, fmt, "wide_" + fmt_name)
+    cut = len(text) // 2
+    res = gpu_parse(env, text[:cut], fmt, False)[0]
+    monkeypatch.delenv("SKH_PARSE_POS64")
+    res_narrow = gpu_parse(env, text[:cut], fmt, False)[0]
+    assert (res.status, res.nrec, res.consumed, res.seq_bytes) == (res_narrow.status, res_narrow.nrec, res_narrow.consumed, res_narrow.seq_bytes)
