@@ -796,7 +796,8 @@ template <bool FASTQ, typename POS>
 __global__ void k_parse_decide(ParseState* st, uint64_t n, int final, uint64_t max_lines,
                                const uint64_t* __restrict__ nlpos, const POS* __restrict__ line_start,
                                const POS* __restrict__ line_dst,
-                               uint64_t max_records, uint64_t* __restrict__ offsets)
+                               uint64_t max_records, uint64_t* __restrict__ offsets, uint64_t seq_capacity,
+                               ParseResult* __restrict__ res)
 {
     const uint64_t L = st->nlines, n_nl = st->n_nl;
     uint64_t nrec = 0, seq_bytes = 0, consumed = 0;
@@ -838,6 +839,15 @@ __global__ void k_parse_decide(ParseState* st, uint64_t n, int final, uint64_t m
     }
     st->status = status; st->nrec = nrec; st->seq_bytes = seq_bytes; st->consumed = consumed;
     if (status == PARSE_OK && nrec <= max_records) offsets[nrec] = seq_bytes;
+    // what the caller reads (the copies that follow change nothing of it)
+    ParseResult r;
+    r.nrec = nrec; r.seq_bytes = seq_bytes; r.consumed = consumed; r.lines = L;
+    r.status = status; r.pad = 0; r.error_line = -1;
+    const unsigned long long err_line = st->err_line;
+    if (r.status == PARSE_OK && err_line != ~0ull) r.status = PARSE_EFORMAT;
+    if (r.status == PARSE_EFORMAT) { r.error_line = (int64_t)err_line; r.nrec = 0; r.seq_bytes = 0; r.consumed = 0; }
+    if (r.status == PARSE_OK && (r.nrec > max_records || r.seq_bytes > seq_capacity)) r.status = PARSE_ECAPACITY;
+    *res = r;
 }
 
 __device__ __forceinline__ uint64_t shfl64(uint64_t v, uint32_t src_lane)
@@ -1095,18 +1105,6 @@ __global__ __launch_bounds__(PB) void k_parse_copy_long(const ParseState* st, ui
             }
         }
     }
-}
-
-__global__ void k_parse_finish(const ParseState* st, uint64_t max_records, uint64_t seq_capacity,
-                               ParseResult* __restrict__ res)
-{
-    ParseResult r;
-    r.nrec = st->nrec; r.seq_bytes = st->seq_bytes; r.consumed = st->consumed; r.lines = st->nlines;
-    r.status = st->status; r.error_line = -1;
-    if (r.status == PARSE_OK && st->err_line != ~0ull) { r.status = PARSE_EFORMAT; }
-    if (r.status == PARSE_EFORMAT) { r.error_line = (int64_t)st->err_line; r.nrec = 0; r.seq_bytes = 0; r.consumed = 0; }
-    if (r.status == PARSE_OK && (r.nrec > max_records || r.seq_bytes > seq_capacity)) r.status = PARSE_ECAPACITY;
-    *res = r;
 }
 
 
@@ -1408,12 +1406,11 @@ static hipError_t launch_parse_t(const uint8_t* text, uint64_t n, int final, uin
     hipLaunchKernelGGL((k_line_scan<FASTQ, POS>), dim3((uint32_t)npart), dim3(PB), 0, s, line_len, line_head, st, part, line_dst,
                        line_start, max_records, offsets, name_pos, name_len);
     hipLaunchKernelGGL((k_parse_decide<FASTQ, POS>), dim3(1), dim3(1), 0, s, st, n, final, max_lines, nlpos, line_start, line_dst,
-                       max_records, offsets);
+                       max_records, offsets, seq_capacity, res);
     hipLaunchKernelGGL((k_parse_copy<FASTQ, POS>), dim3(gc), dim3(PB), 0, s, st, max_records, seq_capacity, text, line_start,
                        line_len, line_head, line_dst, offsets, seq, qual);
     hipLaunchKernelGGL((k_parse_copy_long<FASTQ, POS>), dim3(1024), dim3(PB), 0, s, st, max_records, seq_capacity, text, n,
                        line_start, line_len, line_head, line_dst, offsets, seq, qual);
-    hipLaunchKernelGGL(k_parse_finish, dim3(1), dim3(1), 0, s, st, max_records, seq_capacity, res);
     return hipGetLastError();
 }
 
