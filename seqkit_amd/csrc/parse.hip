@@ -912,6 +912,7 @@ __device__ __forceinline__ void copy_line(uint8_t* __restrict__ out, const uint8
 constexpr uint32_t PC_STAGE = 3584;
 
 template <bool FASTQ, typename POS>
+__attribute__((amdgpu_waves_per_eu(FASTQ ? 5 : 8, FASTQ ? 5 : 8)))
 __global__ __launch_bounds__(PB) void k_parse_copy(const ParseState* st, uint64_t max_records, uint64_t seq_capacity,
                                                    const uint8_t* __restrict__ text,
                                                    const POS* __restrict__ line_start,
